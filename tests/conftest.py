@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test (still part of the default CPU suite)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def sa19_golden():
+    return load_golden("sa19_female_default.npz")
+
+
+@pytest.fixture(scope="session")
+def sa19_signal():
+    from scipy.io import wavfile
+    fs, x = wavfile.read(os.path.join(GOLDEN, "SA19.WAV"))
+    return fs, x / 32768.0
+
+
+def unpack_records(g, a, with_fm=True):
+    """Expand the sparse frame-centre records stored by make_golden.py for adaptation `a`."""
+    shape = tuple(int(v) for v in g["rec%d_shape" % a])
+    mask = np.unpackbits(g["rec%d_mask" % a])[: shape[0] * shape[1]].astype(bool).reshape(shape)
+    out = {"mask": mask, "a0": g["rec%d_a0" % a]}
+    for name in ("am", "ph") + (("fm",) if with_fm else ()):
+        arr = np.zeros(shape)
+        arr[mask] = g["rec%d_%s" % (a, name)]
+        out[name] = arr
+    return out

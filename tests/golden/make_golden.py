@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+Imports the reference implementation from /root/reference *unmodified* (two
+NumPy-2 attribute shims are set in THIS process because SWIPE.py:5-7 imports
+`round_`/`NAN`, removed in NumPy 2), runs it, and captures inputs/outputs of the
+hot path by wrapping module-level names that the reference looks up at call
+time (functions.py:111 swipep, :113 getLinear, :125 voicedUnvoicedFrames,
+:196 iqhmLS_complexamps, :295 eaqhmLS_complexamps, :340 interp1d, :373
+phase_integr_interpolation, :388 std).  Driver locals are read through
+sys._getframe(1).f_locals from inside those wrappers.
+
+Nothing from the reference's source text is written to the fixtures: the .npz
+files hold numeric inputs/outputs only.
+
+Usage:
+    python tests/golden/make_golden.py sa19            # full default run (~4 min)
+    python tests/golden/make_golden.py sa19_vuv        # fullWaveform=False, maxAdpt=1
+    python tests/golden/make_golden.py synth16k        # 2 s synthetic @16 kHz, maxAdpt=3
+    python tests/golden/make_golden.py synth48k        # 0.6 s synthetic @48 kHz, maxAdpt=1
+    python tests/golden/make_golden.py prep            # pre-processing-only fixtures
+    python tests/golden/make_golden.py units           # small unit known-answers
+"""
+import os
+import sys
+import tempfile
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+import numpy as np
+
+np.round_ = np.round  # harness-side shim; reference untouched
+np.NAN = np.nan
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "eaqhm-analysis-and-synthesis-in-python_amd"))
+
+import functions as F  # noqa: E402  (the reference)
+from scipy.io import wavfile  # noqa: E402
+
+from synth import synth_speech_int16  # noqa: E402  (our own generator, shared with bench.py)
+
+
+# --------------------------------------------------------------------------- capture machinery
+class Capture:
+    def __init__(self, ls_frames_iqhm=(), ls_frames_eaqhm=(), dense_adpts=(0,), dense_k=(0, 30, 45),
+                 dense_ranges=((0, 9000), (30000, 36000)), rec_adpts=(0, 1)):
+        self.out = {}
+        self.ls_frames_iqhm = set(ls_frames_iqhm)
+        self.ls_frames_eaqhm = set(ls_frames_eaqhm)
+        self.dense_adpts = set(dense_adpts)
+        self.dense_k = dense_k
+        self.dense_ranges = dense_ranges
+        self.rec_adpts = set(rec_adpts)
+        self.n_iqhm = 0
+        self.n_eaqhm = 0
+        self.n_std = 0
+        self.gl_depth = 0
+        self.shapes_iqhm = []
+        self.shapes_eaqhm = []
+        self.f0_a0 = []
+        self.ti_a0 = []
+        self.stale_f0 = {}
+        self._orig = {}
+
+    def install(self):
+        for name in ("swipep", "getLinear", "voicedUnvoicedFrames", "iqhmLS_complexamps",
+                     "eaqhmLS_complexamps", "interp1d", "std"):
+            self._orig[name] = getattr(F, name)
+        F.swipep = self.swipep
+        F.getLinear = self.getLinear
+        F.voicedUnvoicedFrames = self.vuv
+        F.iqhmLS_complexamps = self.iqhm
+        F.eaqhmLS_complexamps = self.eaqhm
+        F.interp1d = self.interp1d
+        F.std = self.std
+
+    def uninstall(self):
+        for name, fn in self._orig.items():
+            setattr(F, name, fn)
+
+    # -- pre-processing
+    def swipep(self, x, fs, speechFile, plim):
+        r = self._orig["swipep"](x, fs, speechFile, plim)
+        self.out["swipe_track"] = np.array(r, dtype=np.float64)
+        self.out["plim"] = np.array(plim, dtype=np.float64)
+        return r
+
+    def getLinear(self, v, t):
+        self.gl_depth += 1
+        try:
+            r = self._orig["getLinear"](v, t)
+        finally:
+            self.gl_depth -= 1
+        if self.gl_depth == 0:
+            self.out["f0s_5ms"] = np.array(r, dtype=np.float64)
+        return r
+
+    def vuv(self, s, fs, gender):
+        frames, frame_step = self._orig["voicedUnvoicedFrames"](s, fs, gender)
+        self.out["vuv_ti"] = np.array([f.ti for f in frames], dtype=np.int64)
+        self.out["vuv_isSpeech"] = np.array([float(f.isSpeech) for f in frames])
+        self.out["vuv_isVoiced"] = np.array([float(f.isVoiced) for f in frames])
+        self.out["frame_step"] = np.int64(frame_step)
+        return frames, frame_step
+
+    # -- LS seams
+    def iqhm(self, s, f0range, window, fs):
+        amp, slo = self._orig["iqhmLS_complexamps"](s, f0range, window, fs)
+        idx = self.n_iqhm
+        self.n_iqhm += 1
+        self.shapes_iqhm.append((len(s), len(f0range)))
+        loc = sys._getframe(1).f_locals
+        self.f0_a0.append(float(loc["f0"]))
+        self.ti_a0.append(int(loc["tith"]))
+        if idx in self.ls_frames_iqhm:
+            p = "iqhm%d_" % idx
+            self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
+            self.out[p + "f0range"] = np.array(f0range, dtype=np.float64)
+            self.out[p + "window"] = np.array(window, dtype=np.float64)
+            self.out[p + "fs"] = np.int64(fs)
+            self.out[p + "amp"] = np.array(amp).ravel()
+            self.out[p + "slope"] = np.array(slo).ravel()
+            self.out[p + "tith"] = np.int64(loc["tith"])
+        return amp, slo
+
+    def eaqhm(self, s, am, fm, window, fs):
+        amp, slo = self._orig["eaqhmLS_complexamps"](s, am, fm, window, fs)
+        idx = self.n_eaqhm
+        self.n_eaqhm += 1
+        self.shapes_eaqhm.append((len(s), fm.shape[1]))
+        loc = sys._getframe(1).f_locals
+        a = int(loc["a"])
+        self.stale_f0.setdefault(a, float(loc["f0"]))
+        if idx in self.ls_frames_eaqhm:
+            p = "eaqhm%d_" % idx
+            self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
+            self.out[p + "am"] = np.array(am, dtype=np.float64)
+            self.out[p + "fm"] = np.array(fm, dtype=np.float64)
+            self.out[p + "window"] = np.array(window, dtype=np.float64)
+            self.out[p + "fs"] = np.int64(fs)
+            self.out[p + "amp"] = np.array(amp).ravel()
+            self.out[p + "slope"] = np.array(slo).ravel()
+            self.out[p + "tith"] = np.int64(loc["tith"])
+            self.out[p + "a"] = np.int64(a)
+            self.out[p + "slots"] = np.array(loc["fm_current_nonzeros"]).ravel().astype(np.int64)
+        return amp, slo
+
+    # -- frame-centre records (captured when the driver starts the a0 spline, functions.py:340)
+    def interp1d(self, *args, **kw):
+        if kw.get("kind", None) == 3 and "fill_value" in kw:
+            loc = sys._getframe(1).f_locals
+            a = int(loc["a"])
+            ti = np.asarray(loc["ti"])
+            c = ti - 1
+            if a in self.rec_adpts:
+                am = loc["am_recon"][c]
+                mask = am != 0
+                self.out["rec%d_mask" % a] = np.packbits(mask)
+                self.out["rec%d_shape" % a] = np.array(mask.shape, dtype=np.int64)
+                self.out["rec%d_am" % a] = am[mask]
+                self.out["rec%d_ph" % a] = loc["ph_recon"][c][mask]
+                if a > 0:
+                    self.out["rec%d_fm" % a] = loc["fm_recon"][c][mask]
+                self.out["rec%d_a0" % a] = np.array(loc["a0_recon"][c])
+            # checksums for every adaptation
+            self.out["recsum%d" % a] = np.array([
+                np.count_nonzero(loc["am_recon"][c]),
+                loc["am_recon"][c].sum(), loc["fm_recon"][c].sum(),
+                np.abs(loc["ph_recon"][c]).sum(), loc["a0_recon"][c].sum()])
+        return self._orig["interp1d"](*args, **kw)
+
+    # -- dense state after interpolation + synthesis (functions.py:388)
+    def std(self, x, *args, **kw):
+        r = self._orig["std"](x, *args, **kw)
+        fr = sys._getframe(1)
+        if fr.f_code.co_name == "eaQHMAnalysisAndSynthesis" and "s_recon_tmp" in fr.f_locals:
+            loc = fr.f_locals
+            a = int(loc["a"])
+            if a in self.dense_adpts:
+                for k in self.dense_k:
+                    if k >= loc["am_recon"].shape[1]:
+                        continue
+                    for (lo, hi) in self.dense_ranges:
+                        hi = min(hi, loc["am_recon"].shape[0])
+                        if lo >= hi:
+                            continue
+                        p = "dense%d_k%d_%d_" % (a, k, lo)
+                        self.out[p + "am"] = np.array(loc["am_recon"][lo:hi, k])
+                        self.out[p + "fm"] = np.array(loc["fm_recon"][lo:hi, k])
+                        self.out[p + "ph"] = np.array(loc["ph_recon"][lo:hi, k])
+                        self.out[p + "fmcur"] = np.array(loc["fm_current"][lo:hi, k])
+                a0 = loc["a0_recon"]
+                self.out["dense%d_a0_head" % a] = np.array(a0[:9000])
+                self.out["dense%d_a0_tail" % a] = np.array(a0[-2000:])
+                self.out["dense%d_srecon" % a] = np.array(loc["s_recon_tmp"])
+            self.out["densesum%d" % a] = np.array([
+                loc["am_recon"].sum(), loc["fm_recon"].sum(), np.abs(loc["ph_recon"]).sum(),
+                loc["fm_current"].sum(), loc["a0_recon"].sum(), loc["s_recon_tmp"].sum(),
+                np.count_nonzero(loc["am_recon"]), np.count_nonzero(loc["fm_current"])])
+        return r
+
+
+def pack_det(det, prefix, out):
+    """Flatten the returned Deterministic list (functions.py:404-411) into arrays."""
+    n = len(det)
+    out[prefix + "ti"] = np.array([int(d.ti) for d in det], dtype=np.int64)
+    out[prefix + "isSpeech"] = np.array([bool(d.isSpeech) for d in det])
+    out[prefix + "isVoiced"] = np.array([bool(d.isVoiced) for d in det])
+    a0 = np.zeros(n)
+    lens = np.zeros(n, dtype=np.int64)
+    vals_am, vals_fm, vals_pk, slots = [], [], [], []
+    for i, d in enumerate(det):
+        if not d.isVoiced:
+            continue
+        a0[i] = float(d.a0)
+        amp = d.amplitudes
+        lens[i] = len(amp)
+        for k in range(len(amp)):
+            e = amp[k]
+            if isinstance(e, np.ndarray):
+                slots.append((i, k))
+                vals_am.append(float(e[0]))
+                vals_fm.append(float(d.frange[k][0]))
+                vals_pk.append(float(d.pk[k][0]))
+    out[prefix + "a0"] = a0
+    out[prefix + "len"] = lens
+    out[prefix + "cells"] = np.array(slots, dtype=np.int32).reshape(-1, 2)
+    out[prefix + "am"] = np.array(vals_am)
+    out[prefix + "fm"] = np.array(vals_fm)
+    out[prefix + "pk"] = np.array(vals_pk)
+    # type quirks of one voiced struct, recorded as strings
+    for d in det:
+        if d.isVoiced:
+            out[prefix + "quirk"] = np.array([
+                type(d.ti).__name__, type(d.a0).__name__, str(d.amplitudes.dtype), str(np.shape(d.amplitudes)),
+                type(d.amplitudes[0]).__name__, str(np.shape(d.amplitudes[0])), repr(d.ak),
+                str(d.frange.dtype), str(d.pk.dtype)])
+            break
+
+
+def run_reference(wav, gender, cap, **kw):
+    cap.install()
+    try:
+        s_recon, SRER, det, T = F.eaQHMAnalysisAndSynthesis(wav, gender, loadingScreen=False, printPrompts=False, **kw)
+    finally:
+        cap.uninstall()
+    o = cap.out
+    o["SRER"] = np.array([float(x) for x in SRER])
+    o["s_recon"] = np.array(s_recon, dtype=np.float64)
+    o["ref_seconds"] = np.float64(T)
+    o["ls_shapes_iqhm"] = np.array(cap.shapes_iqhm, dtype=np.int32)
+    o["ls_shapes_eaqhm"] = np.array(cap.shapes_eaqhm, dtype=np.int32)
+    o["f0_a0"] = np.array(cap.f0_a0)
+    o["ti_a0"] = np.array(cap.ti_a0, dtype=np.int64)
+    o["stale_f0"] = np.array([[a, f] for a, f in sorted(cap.stale_f0.items())], dtype=np.float64).reshape(-1, 2)
+    pack_det(det, "det_", o)
+    return o
+
+
+def save(name, o):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **o)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "SRER" in o and o["SRER"])
+
+
+def write_wav_int16(x, fs):
+    f = tempfile.NamedTemporaryFile(suffix=".wav", delete=False)
+    f.close()
+    wavfile.write(f.name, fs, x.astype(np.int16))
+    return f.name
+
+
+# --------------------------------------------------------------------------- jobs
+def job_sa19():
+    cap = Capture(ls_frames_iqhm=(0, 700, 2000, 3500), ls_frames_eaqhm=(0, 700, 2000, 3500),
+                  dense_adpts=(0,), rec_adpts=(0, 1))
+    o = run_reference(os.path.join(REF, "SA19.WAV"), "female", cap)
+    save("sa19_female_default.npz", o)
+
+
+def job_sa19_vuv():
+    cap = Capture(dense_adpts=(), rec_adpts=())
+    o = run_reference(os.path.join(REF, "SA19.WAV"), "female", cap, fullWaveform=False, maxAdpt=1)
+    for k in [k for k in o if k.startswith("recsum") or k.startswith("densesum")]:
+        pass
+    # keep it small: drop per-cell Deterministic values, keep flags + SRER + s_recon
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    save("sa19_female_voicedonly_adpt1.npz", o)
+
+
+def job_synth16k():
+    fs = 16000
+    x = synth_speech_int16(2.0, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(dense_adpts=(), rec_adpts=(0,))
+    o = run_reference(wav, "female", cap, maxAdpt=3)
+    o["wav_int16"] = x
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    os.unlink(wav)
+    save("synth16k_2s_adpt3.npz", o)
+
+
+def job_synth48k():
+    fs = 48000
+    x = synth_speech_int16(0.6, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(ls_frames_iqhm=(100,), dense_adpts=(), rec_adpts=(0,))
+    o = run_reference(wav, "female", cap, maxAdpt=1)
+    o["wav_int16"] = x
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    os.unlink(wav)
+    save("synth48k_0p6s_adpt1.npz", o)
+
+
+def prep_only(x_int16, fs, gender):
+    """Run only the reference's pre-processing (functions.py:86-125) on an int16 signal."""
+    s = F.transpose1dArray(x_int16 / F.normalize)
+    f0min, f0max = {"male": (70, 180), "female": (160, 300), "child": (300, 600)}.get(gender, (70, 500))
+    f0s = F.swipep(F.transpose(s)[0], fs, None, [f0min, f0max])
+    track = np.array(f0s)
+    f0s = F.getLinear(f0s, F.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, frame_step = F.voicedUnvoicedFrames(s, fs, gender)
+    return dict(
+        f0s_5ms=np.array(f0s), swipe_f0_min=np.float64(np.min(track[:, 1])),
+        vuv_ti=np.array([f.ti for f in frames], dtype=np.int64),
+        vuv_isSpeech=np.array([float(f.isSpeech) for f in frames]),
+        vuv_isVoiced=np.array([float(f.isVoiced) for f in frames]),
+        frame_step=np.int64(frame_step), fs=np.int64(fs), n_samples=np.int64(len(x_int16)))
+
+
+def job_prep():
+    fs, x = wavfile.read(os.path.join(REF, "SA19.WAV"))
+    o = {}
+    for rep in (2, 4, 8, 10):
+        r = prep_only(np.tile(x, rep), fs, "female")
+        for k, v in r.items():
+            o["sa19x%d_%s" % (rep, k)] = v
+        print("prep sa19 x%d done" % rep, flush=True)
+    for dur, fs2 in ((60.0, 16000), (20.0, 48000)):
+        xs = synth_speech_int16(dur, fs2)
+        r = prep_only(xs, fs2, "female")
+        for k, v in r.items():
+            o["synth%dk_%ds_%s" % (fs2 // 1000, int(dur), k)] = v
+        print("prep synth", dur, fs2, "done", flush=True)
+    # keep only column 1 (f0) of the 5 ms grids: column 0 is the query time, column 2 the strength
+    for k in list(o):
+        if k.endswith("f0s_5ms"):
+            o[k] = np.ascontiguousarray(o[k][:, :2])
+    save("prep_fixtures.npz", o)
+
+
+def job_units():
+    """Small known-answer vectors produced by calling reference seams directly."""
+    rng = np.random.default_rng(7)
+    o = {}
+    # phase_integr_interpolation (functions.py:537-575): 4 knots, 46 samples
+    n = 46
+    knots = np.array([0, 15, 30, 45])
+    fm = 2 * np.pi / 16000 * (200 + 30 * np.sin(np.arange(n) / 7.0))
+    ph = np.zeros(n)
+    ph[knots] = rng.uniform(-np.pi, np.pi, 4)
+    o["pii_fm"], o["pii_ph"], o["pii_knots"] = fm, ph, knots
+    o["pii_out"] = F.phase_integr_interpolation(fm.copy(), ph.copy(), knots)
+    # iqhm / eaqhm on small random problems
+    N, K = 61, 3
+    f0 = 210.0
+    f0range = np.arange(-K, K + 1) * f0
+    w = np.blackman(N)
+    s = rng.standard_normal((N, 1)) * 0.1
+    a, b = F.iqhmLS_complexamps(s, f0range, w, 16000)
+    o["iq_s"], o["iq_f0range"], o["iq_w"], o["iq_amp"], o["iq_slope"] = s.ravel(), f0range, w, a.ravel(), b.ravel()
+    Kc = 2 * K + 1
+    fmw = np.tile(f0range, (N, 1)) + rng.standard_normal((N, Kc)) * 2.0
+    amw = np.abs(rng.standard_normal((N, Kc))) * 0.05 + 0.02
+    wh = np.hamming(N)
+    a, b = F.eaqhmLS_complexamps(s, amw, fmw, wh, 16000)
+    o["ea_s"], o["ea_am"], o["ea_fm"], o["ea_w"], o["ea_amp"], o["ea_slope"] = s.ravel(), amw, fmw, wh, a.ravel(), b.ravel()
+    # getLinear (functions.py:644-680)
+    v = np.column_stack([np.arange(0, 0.05, 0.001), rng.uniform(100, 300, 50), rng.uniform(0, 1, 50)])
+    t = np.arange(0, 0.048, 0.005)
+    o["gl_v"], o["gl_t"], o["gl_out"] = v, t, F.getLinear(v, t)
+    # medfilt (misc.py:184-206) on a boolean pattern
+    import misc
+    xb = rng.uniform(size=40) > 0.5
+    o["mf_x"], o["mf_out"] = xb, np.array(misc.medfilt(xb, 5), dtype=np.float64)
+    # arrayByIndex / mytranspose shapes (misc.py:31-93)
+    r = misc.arrayByIndex(np.array([[0], [2], [5]]), np.array([[1.5], [2.5], [3.5]]))
+    o["abi_dtype"] = np.array([str(r.dtype), str(r.shape), type(r[1]).__name__, str(np.shape(r[0]))])
+    save("unit_vectors.npz", o)
+
+
+if __name__ == "__main__":
+    jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
+                prep=job_prep, units=job_units)
+    for j in sys.argv[1:]:
+        jobs[j]()
