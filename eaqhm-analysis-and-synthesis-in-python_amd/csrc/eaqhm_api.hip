@@ -1,0 +1,52 @@
+// eaqhm_api.hip — context life cycle of libeaqhm_hip.so.
+#include "eaqhm_common.h"
+
+extern "C" int eaqhm_ctx_create(eaqhm_ctx** out, int device) {
+  if (!out) return EAQHM_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return EAQHM_EHIP;
+  if (hipSetDevice(device) != hipSuccess) return EAQHM_EHIP;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return EAQHM_EHIP;
+  eaqhm_ctx* c = new eaqhm_ctx();
+  c->device = device;
+  c->n_cu = p.multiProcessorCount;
+  c->lds_bytes = (int)p.sharedMemPerBlock;
+  c->clock_khz = p.clockRate;
+  *out = c;
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_ctx_destroy(eaqhm_ctx* ctx) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (ctx->scratch) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->scratch);
+  }
+  delete ctx;
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_set_stream(eaqhm_ctx* ctx, void* hip_stream) {
+  if (!ctx) return EAQHM_EINVAL;
+  ctx->stream = (hipStream_t)hip_stream;
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_sync(eaqhm_ctx* ctx) {
+  if (!ctx) return EAQHM_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EAQHM_OK;
+}
+
+extern "C" const char* eaqhm_last_error(eaqhm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]) {
+  if (!ctx || !h_info) return EAQHM_EINVAL;
+  h_info[0] = ctx->n_cu;
+  h_info[1] = ctx->lds_bytes;
+  h_info[2] = ctx->clock_khz;
+  h_info[3] = EAQHM_ABI_VERSION;
+  return EAQHM_OK;
+}

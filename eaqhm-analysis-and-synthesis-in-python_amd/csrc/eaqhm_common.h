@@ -1,0 +1,53 @@
+// eaqhm_common.h — shared by the HIP translation units of libeaqhm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/eaqhm_hip.h"
+
+#define EAQHM_ABI_VERSION 1
+
+struct eaqhm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 0;
+  int lds_bytes = 0;
+  int clock_khz = 0;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  char err[512] = {0};
+
+  int fail(int code, const char* msg) {
+    snprintf(err, sizeof(err), "%s", msg);
+    return code;
+  }
+  // grow-only scratch; growing synchronises the stream first (never happens in steady state)
+  int reserve(size_t bytes) {
+    if (bytes <= scratch_bytes) return EAQHM_OK;
+    if (scratch) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return fail(EAQHM_EHIP, "scratch: stream sync failed");
+      (void)hipFree(scratch);
+      scratch = nullptr;
+      scratch_bytes = 0;
+    }
+    if (hipMalloc(&scratch, bytes) != hipSuccess) {
+      snprintf(err, sizeof(err), "scratch: hipMalloc(%zu bytes) failed", bytes);
+      return EAQHM_ENOMEM;
+    }
+    scratch_bytes = bytes;
+    return EAQHM_OK;
+  }
+};
+
+#define HIP_TRY(ctx, call)                                                                        \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+               __FILE__, __LINE__);                                                               \
+      return EAQHM_EHIP;                                                                          \
+    }                                                                                             \
+  } while (0)

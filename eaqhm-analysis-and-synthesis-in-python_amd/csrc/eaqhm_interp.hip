@@ -1,0 +1,355 @@
+// eaqhm_interp.hip — track interpolation, phase integration, additive synthesis and SRER.
+// gfx950 (MI355X) only, FP64.
+//
+//   eaqhm_spline_kernel   one thread per harmonic slot (+1 for a0) walks the instants: runs of
+//                         consecutive accepted instants (functions.py:350-362) and the not-a-knot cubic
+//                         systems on their knots (functions.py:340, :367; interp1d(kind=3)).
+//   eaqhm_eval_kernel     one thread per sample, loop over slots: linear am (functions.py:364), cubic fm
+//                         (:367-371 incl. the padded <4-knot case), phase by frequency integration with the
+//                         sine-bump correction (functions.py:537-575), next-iteration frequency from the
+//                         unwrapped phase (:375), synthesis a0 + 2*sum am*cos(ph) (:385) and the partial
+//                         sums of the reconstruction error (:388).  Every (slot, sample) cell of the two
+//                         dense outputs is written, so no memset is needed between adaptations.
+//   eaqhm_srer_kernel     deterministic final reduction + SRER in dB.
+//
+// Bandwidth-type stage: per adaptation it reads (1+3*Kmax)*8*No_ti bytes of records and writes
+// 2*Kmax*8*L bytes of dense tracks (the reference keeps seven dense L x Kmax arrays; only am_current and
+// fm_current are ever read again, so only those two are materialised here).
+#include "eaqhm_common.h"
+
+namespace eaqhm {
+
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void eaqhm_spline_kernel(const double* __restrict__ records,
+                                               int No_ti, int Kmax, int step, unsigned char* __restrict__ code,
+                                               double* __restrict__ mom, double* __restrict__ work) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > Kmax) return;
+  const int ld = Kmax + 1, RS = 3 * Kmax + 1;
+  const double h2 = (double)step * (double)step;
+  double* cp = work;                       // [No_ti][ld]
+  double* dp = work + (size_t)No_ti * ld;  // [No_ti][ld]
+  auto Y = [&](int i) -> double {
+    return (k == Kmax) ? records[(size_t)i * RS + 3 * Kmax] : records[(size_t)i * RS + Kmax + k];
+  };
+  auto ACC = [&](int i) -> bool { return (k == Kmax) ? true : (records[(size_t)i * RS + k] != 0.0); };
+  auto D2 = [&](int i) -> double { return 6.0 * ((Y(i - 1) - 2.0 * Y(i)) + Y(i + 1)) / h2; };
+
+  int rs = -1;
+  for (int i = 0; i <= No_ti; ++i) {
+    const bool a = (i < No_ti) && ACC(i);
+    if (a) {
+      if (rs < 0) rs = i;
+      continue;
+    }
+    if (i < No_ti) {
+      mom[(size_t)i * ld + k] = 0.0;
+      if (k < Kmax) code[(size_t)i * Kmax + k] = 0;
+    }
+    if (rs < 0) continue;
+    const int m = i - rs;  // run rs .. i-1
+    if (m < 4) {
+      for (int q = 0; q < m; ++q) {
+        mom[(size_t)(rs + q) * ld + k] = 0.0;
+        if (k < Kmax) code[(size_t)(rs + q) * Kmax + k] = (m == 1) ? 1 : (unsigned char)(16 + 4 * m + q);
+      }
+    } else {
+      // not-a-knot, uniform spacing: 6*M_1 = d_1, 6*M_{m-2} = d_{m-2}; (1,4,1) system in between
+      const double M1 = D2(rs + 1) / 6.0;
+      const double Mm2 = D2(rs + m - 2) / 6.0;
+      if (m >= 5) {
+        double cprev = 0.0, dprev = 0.0;
+        for (int q = 2; q <= m - 3; ++q) {
+          double rhs = D2(rs + q);
+          if (q == 2) rhs -= M1;
+          if (q == m - 3) rhs -= Mm2;
+          double den = (q == 2) ? 4.0 : 4.0 - cprev;
+          double cq = 1.0 / den;
+          double dq = ((q == 2) ? rhs : rhs - dprev) / den;
+          cp[(size_t)(rs + q) * ld + k] = cq;
+          dp[(size_t)(rs + q) * ld + k] = dq;
+          cprev = cq; dprev = dq;
+        }
+        double Mnext = dprev;
+        mom[(size_t)(rs + m - 3) * ld + k] = Mnext;
+        for (int q = m - 4; q >= 2; --q) {
+          double Mq = dp[(size_t)(rs + q) * ld + k] - cp[(size_t)(rs + q) * ld + k] * Mnext;
+          mom[(size_t)(rs + q) * ld + k] = Mq;
+          Mnext = Mq;
+        }
+      }
+      mom[(size_t)(rs + 1) * ld + k] = M1;
+      mom[(size_t)(rs + m - 2) * ld + k] = Mm2;
+      const double M2 = mom[(size_t)(rs + 2) * ld + k];
+      const double Mm3 = mom[(size_t)(rs + m - 3) * ld + k];
+      mom[(size_t)rs * ld + k] = 2.0 * M1 - M2;
+      mom[(size_t)(rs + m - 1) * ld + k] = 2.0 * Mm2 - Mm3;
+      if (k < Kmax)
+        for (int q = 0; q < m; ++q) code[(size_t)(rs + q) * Kmax + k] = 2;
+    }
+    rs = -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct EvalArgs {
+  const double* records; const unsigned char* code; const double* mom;
+  int No_ti; int Kmax; int step; double fs; long long L; long long t_lo; long long t_hi; long long s_lo; long long s_hi;
+  const double* target; double* am_out; double* fm_out; double* ph_knot; double* s_hat; double* partials;
+};
+
+struct Slot {
+  const EvalArgs& A;
+  int k;
+  __device__ double am(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + k]; }
+  __device__ double fm(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + A.Kmax + k]; }
+  __device__ double ph(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + 2 * A.Kmax + k]; }
+  __device__ int code(int i) const { return (i >= 0 && i < A.No_ti) ? A.code[(size_t)i * A.Kmax + k] : 0; }
+  __device__ double mom(int i) const { return A.mom[(size_t)i * (A.Kmax + 1) + k]; }
+};
+
+// cubic piece of the interval (i, i+1) at offset r samples from knot i
+__device__ inline double spline_piece(double y0, double y1, double m0, double m1, double r, double h) {
+  double u = r / h, v = 1.0 - u;
+  return v * y0 + u * y1 + (h * h / 6.0) * ((v * v * v - v) * m0 + (u * u * u - u) * m1);
+}
+
+// fm_recon on the interval (i, i+1), both ends accepted, r in [0, step]
+struct FmPiece {
+  int kind;  // 2: spline piece, 3: single cubic through 4 points (short run, functions.py:368-371)
+  double y0, y1, m0, m1, h;
+  double px[4], py[4], x0;  // Lagrange nodes for the short-run case
+  __device__ double operator()(int r) const {
+    if (kind == 2) return spline_piece(y0, y1, m0, m1, (double)r, h);
+    double x = x0 + (double)r, acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      double l = py[p];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q != p) l *= (x - px[q]) / (px[p] - px[q]);
+      acc += l;
+    }
+    return acc;
+  }
+};
+
+__device__ inline FmPiece make_piece(const Slot& S, int i, int ci) {
+  FmPiece P;
+  const int step = S.A.step;
+  P.h = (double)step;
+  P.x0 = (double)i * P.h;
+  if (ci == 2) {
+    P.kind = 2;
+    P.y0 = S.fm(i); P.y1 = S.fm(i + 1); P.m0 = S.mom(i); P.m1 = S.mom(i + 1);
+  } else {
+    P.kind = 3;
+    const int m = (ci - 16) >> 2, pos = (ci - 16) & 3;
+    const int rs = i - pos;
+    const int npad = 4 - m;  // knots at samples 0, step, ... carry whatever fm_recon holds there
+    for (int p = 0; p < npad; ++p) {
+      P.px[p] = (double)(p * step);
+      P.py[p] = (p < S.A.No_ti && S.code(p) != 0) ? S.fm(p) : 0.0;
+    }
+    for (int q = 0; q < m; ++q) {
+      P.px[npad + q] = (double)(rs + q) * P.h;
+      P.py[npad + q] = S.fm(rs + q);
+    }
+  }
+  return P;
+}
+
+// numpy.unwrap on one step: the unwrapped difference
+__device__ inline double unwrap_diff(double dd) {
+  if (fabs(dd) < M_PI) return dd;
+  double m = fmod(dd + M_PI, 2.0 * M_PI);
+  if (m < 0) m += 2.0 * M_PI;
+  m -= M_PI;
+  if (m == -M_PI && dd > 0) m = M_PI;
+  return m;
+}
+
+// phase_integr_interpolation (functions.py:537-575) on one knot interval; returns the integrated and
+// corrected phase at offsets ra and rb (0 <= ra, rb <= D)
+__device__ inline void integrate_interval(const FmPiece& P, double phi0, double phi1, int D, double fs,
+                                          const double* ft, int ra, int rb, double& pa, double& pb) {
+  const double scale = 2.0 * M_PI / fs;
+  double w0 = scale * P(0);
+  double acc = w0, sa = w0, sb = w0;
+  for (int u = 1; u <= D; ++u) {
+    acc += scale * P(u);
+    if (u == ra) sa = acc;
+    if (u == rb) sb = acc;
+  }
+  const double shift = phi0 - w0;
+  const double pend = acc + shift;
+  const double e = pend - phi1;
+  const double Mr = rint(e / (2.0 * M_PI));
+  const double er = M_PI * (e - 2.0 * M_PI * Mr) / (2.0 * (double)D);
+  double c = 0.0, ca = 0.0, cb = 0.0;
+  for (int u = 0; u <= D; ++u) {
+    c += ft[u] * er;
+    if (u == ra) ca = c;
+    if (u == rb) cb = c;
+  }
+  pa = (sa + shift) - ca;
+  pb = (sb + shift) - cb;
+}
+
+extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* ft = lds;                 // step+1
+  double* red = lds + A.step + 1;   // 2*4
+  const int D = A.step;
+  for (int u = threadIdx.x; u <= D; u += blockDim.x) ft[u] = sin(M_PI * (double)u / (double)D);
+  __syncthreads();
+  const long long t = A.t_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < A.t_hi;
+  double dsum = 0.0, dsq = 0.0;
+  if (live) {
+    int i = (int)(t / D);
+    int r = (int)(t - (long long)i * D);
+    if (i >= A.No_ti) { i = A.No_ti - 1; r = (int)(t - (long long)i * D); }  // beyond the last instant
+    const bool past = (i == A.No_ti - 1) && (r > 0);
+    double synth = 0.0;
+    for (int k = 0; k < A.Kmax; ++k) {
+      Slot S{A, k};
+      double amv = 0.0, phv = 0.0, fnext = 0.0;
+      const int ci = S.code(i);
+      if (!past && r > 0) {
+        const int cn = S.code(i + 1);
+        if (ci != 0 && cn != 0) {  // inside the active interval (i, i+1)
+          const double x0 = (double)i * (double)D, x1 = (double)(i + 1) * (double)D;
+          const double a0v = S.am(i), a1v = S.am(i + 1);
+          amv = ((a1v - a0v) / (x1 - x0)) * ((double)t - x0) + a0v;
+          FmPiece P = make_piece(S, i, ci);
+          double pr, pm;
+          integrate_interval(P, S.ph(i), S.ph(i + 1), D, A.fs, ft, r, r - 1, pr, pm);
+          phv = pr;
+          fnext = A.fs / (2.0 * M_PI) * unwrap_diff(pr - pm);
+        }
+      } else if (!past || r == 0) {
+        if (r == 0 && ci != 0) {  // on a knot
+          amv = S.am(i);
+          const bool prev = S.code(i - 1) != 0, next = S.code(i + 1) != 0;
+          if (!prev && !next) {
+            phv = S.ph(i);  // isolated accepted instant: frame-centre values stay as written
+          } else {
+            double pD = 0.0, pDm1 = 0.0;
+            if (prev) {
+              FmPiece Pp = make_piece(S, i - 1, S.code(i - 1));
+              integrate_interval(Pp, S.ph(i - 1), S.ph(i), D, A.fs, ft, D, D - 1, pD, pDm1);
+            }
+            if (next) {
+              FmPiece P = make_piece(S, i, ci);
+              double w0 = (2.0 * M_PI / A.fs) * P(0);
+              phv = w0 + (S.ph(i) - w0);  // first sample of the next interval overwrites the knot
+              if (!prev) fnext = P(0);    // first sample of the run keeps fm_recon (functions.py:375)
+            } else {
+              phv = pD;                   // last knot of a run keeps the integrated phase
+            }
+            if (prev) fnext = A.fs / (2.0 * M_PI) * unwrap_diff(phv - pDm1);
+          }
+          A.ph_knot[(size_t)i * A.Kmax + k] = phv;
+        } else if (r == 0) {
+          A.ph_knot[(size_t)i * A.Kmax + k] = 0.0;
+        }
+      }
+      A.am_out[(size_t)k * A.L + t] = amv;
+      A.fm_out[(size_t)k * A.L + t] = fnext;
+      if (amv != 0.0) synth += amv * cos(phv);
+    }
+    // a0: not-a-knot spline through every instant, extrapolated past the last one (functions.py:340)
+    int ia = i;
+    if (ia > A.No_ti - 2) ia = A.No_ti - 2;
+    const int ld = A.Kmax + 1;
+    const size_t RS = 3 * (size_t)A.Kmax + 1;
+    double a0v = spline_piece(A.records[(size_t)ia * RS + RS - 1], A.records[(size_t)(ia + 1) * RS + RS - 1],
+                              A.mom[(size_t)ia * ld + A.Kmax],
+                              A.mom[(size_t)(ia + 1) * ld + A.Kmax], (double)(t - (long long)ia * D), (double)D);
+    const double sh = a0v + 2.0 * synth;
+    A.s_hat[t] = sh;
+    if (t >= A.s_lo && t < A.s_hi) {
+      const double d = A.target[t] - sh;
+      dsum = d; dsq = d * d;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    dsum += __shfl_xor(dsum, o);
+    dsq += __shfl_xor(dsq, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * (threadIdx.x >> 6)] = dsum;
+    red[2 * (threadIdx.x >> 6) + 1] = dsq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    A.partials[2 * (size_t)blockIdx.x] = a;
+    A.partials[2 * (size_t)blockIdx.x + 1] = b;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double* partials, long long nblocks, double n,
+                                                                    double std_det, double* sums_out) {
+  __shared__ double red[8];
+  double a = 0, b = 0;
+  for (long long q = threadIdx.x; q < nblocks; q += blockDim.x) { a += partials[2 * q]; b += partials[2 * q + 1]; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = red[0] + red[2] + red[4] + red[6];
+    b = red[1] + red[3] + red[5] + red[7];
+    double mean = a / n;
+    double var = b / n - mean * mean;
+    sums_out[0] = a; sums_out[1] = b; sums_out[2] = n;
+    sums_out[3] = 20.0 * log10(std_det / sqrt(var));
+  }
+}
+
+}  // namespace eaqhm
+
+using namespace eaqhm;
+
+extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti,
+                                  int32_t Kmax, int32_t step, uint8_t* code, double* mom, double* work) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (!records || !code || !mom || !work || Kmax <= 0 || step <= 0)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: bad argument");
+  if (No_ti < 4) return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: need at least 4 analysis instants (interp1d kind=3)");
+  const int threads = 64, blocks = (Kmax + 1 + threads - 1) / threads;
+  hipLaunchKernelGGL(eaqhm_spline_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, records, No_ti, Kmax, step,
+                     code, mom, work);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}
+
+extern "C" int64_t eaqhm_eval_partials_len(int64_t t_lo, int64_t t_hi, int32_t step) {
+  (void)step;
+  if (t_hi <= t_lo) return 2;
+  return 2 * ((t_hi - t_lo + 255) / 256);
+}
+
+extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uint8_t* code,
+                                const double* mom, int32_t No_ti, int32_t Kmax, int32_t step, double fs, int64_t L,
+                                int64_t t_lo, int64_t t_hi, int64_t s_lo, int64_t s_hi, const double* target,
+                                double std_det, double* am_out,
+                                double* fm_out, double* ph_knot, double* s_hat, double* partials, double* sums_out) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (!records || !code || !mom || !target || !am_out || !fm_out || !ph_knot || !s_hat || !partials ||
+      !sums_out || No_ti < 4 || Kmax <= 0 || step <= 0 || fs <= 0 || L <= 0 || t_lo < 0 || t_hi > L || t_lo >= t_hi || s_lo < t_lo || s_hi > t_hi || s_lo >= s_hi)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: bad argument");
+  if ((int64_t)(No_ti - 1) * step >= L) return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: instants beyond the signal");
+  EvalArgs A{records, code, mom, No_ti, Kmax, step, fs, (long long)L, (long long)t_lo, (long long)t_hi,
+             (long long)s_lo, (long long)s_hi, target, am_out, fm_out, ph_knot, s_hat, partials};
+  const long long nblocks = (t_hi - t_lo + 255) / 256;
+  size_t lds_bytes = ((size_t)step + 1 + 8) * sizeof(double);
+  hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, (double)(s_hi - s_lo),
+                     std_det, sums_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}

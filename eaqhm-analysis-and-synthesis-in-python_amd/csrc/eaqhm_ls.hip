@@ -1,0 +1,529 @@
+// eaqhm_ls.hip — per-frame weighted complex least squares of the eaQHM analysis, batched over frames.
+// gfx950 (MI355X) only.  FP64 throughout: the reference is float64/complex128 (functions.py:420-535).
+//
+// One workgroup owns one frame at a time (persistent grid-stride over frames) and runs four phases:
+//   A  basis      window the tracks of the active slots, bridge zero gaps, running-sum phases,
+//                 E2 = (am+eps)/(am_mid+eps) * exp(j*2*pi*F/fs); negative/DC/positive column layout
+//                 (functions.py:244-292, :508-519; adaptation 0: functions.py:444-455)
+//   B  Gramian    G_p = E2^H diag(w^2 n^p) E2, p = 0,1,2, and the right-hand sides, which come for
+//                 free by appending the signal window as one more basis column (functions.py:457-464)
+//   C  solve      Cholesky of [[G0,G1],[G1,G2]] with the RHS carried as an extra row (forward solve
+//                 for free), then back substitution (replaces inv(R) @ arr, functions.py:465 / :530)
+//   D  epilogue   frequency mismatch, acceptance, frame-centre records (functions.py:297-324)
+//
+// Column order of the LS unknowns: [n negative columns | DC | n positive columns], Kc = 2n+1, then the
+// same again for the slopes (functions.py:455 / :519: E = [E2, n*E2]).
+#include "eaqhm_common.h"
+
+namespace eaqhm {
+
+// ------------------------------------------------------------------------------------------------
+// scratch carve-up (doubles) for one workgroup
+struct LsScratch {
+  double* Q;    // (Nmax+1) * nmax   running sums relative to the window middle, row u+1 <-> sample u
+  double* r;    // (Nmax+1) * nmax   amplitude ratios
+  double* Xre;  // Nmax * C1max      basis, [t][col], col fastest; C1 = Kc + 1 (signal column last)
+  double* Xim;
+  double* Lt;   // (Mmax) * (Mmax+1) * 2   transposed system matrix: Lt[k][i] = R[i][k], i in [k, M]
+};
+
+__host__ __device__ inline size_t ls_scratch_doubles(int nmax, int Nmax, int Kcmax) {
+  size_t C1 = (size_t)Kcmax + 1, M = 2 * (size_t)Kcmax;
+  return 2 * (size_t)(Nmax + 1) * nmax + 2 * (size_t)Nmax * C1 + 2 * M * (M + 1);
+}
+
+__device__ inline LsScratch carve(double* base, int nmax, int Nmax, int Kcmax) {
+  LsScratch s;
+  size_t C1 = (size_t)Kcmax + 1;
+  s.Q = base;
+  s.r = s.Q + (size_t)(Nmax + 1) * nmax;
+  s.Xre = s.r + (size_t)(Nmax + 1) * nmax;
+  s.Xim = s.Xre + (size_t)Nmax * C1;
+  s.Lt = s.Xim + (size_t)Nmax * C1;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase B: Gramian of the augmented basis -> transposed system matrix Lt (row k holds column k of R,
+// entries i = k..M, row stride ldl complex).  One thread per (a, b) pair, a >= b, of the C1 columns.
+__device__ void gram_to_system(const double* __restrict__ Xre, const double* __restrict__ Xim, int N, int Kc,
+                               int ldx, const double* __restrict__ ww, double mid, double* __restrict__ Lt,
+                               int ldl) {
+  const int C1 = Kc + 1;
+  const int M = 2 * Kc;
+  const int npairs = C1 * (C1 + 1) / 2;
+  for (int p = threadIdx.x; p < npairs; p += blockDim.x) {
+    int a = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    while (a * (a + 1) / 2 > p) --a;
+    int b = p - a * (a + 1) / 2;
+    if (a == Kc && b == Kc) continue;
+    double g0r = 0, g0i = 0, g1r = 0, g1i = 0, g2r = 0, g2i = 0;
+    for (int t = 0; t < N; ++t) {
+      double ar = Xre[(size_t)t * ldx + a], ai = Xim[(size_t)t * ldx + a];
+      double br = Xre[(size_t)t * ldx + b], bi = Xim[(size_t)t * ldx + b];
+      double pr = ar * br + ai * bi;  // conj(xa) * xb
+      double pi = ar * bi - ai * br;
+      double w0 = ww[t], nn = (double)t - mid, w1 = w0 * nn, w2 = w1 * nn;
+      g0r += w0 * pr; g0i += w0 * pi;
+      g1r += w1 * pr; g1i += w1 * pi;
+      g2r += w2 * pr; g2i += w2 * pi;
+    }
+    // G_p[a][b] = sum conj(x_a) x_b.  R = [[G0, G1], [G1, G2]] (Hermitian); Lt[col][row] = R[row][col].
+    auto put = [&](int row, int col, double re, double im) {
+      size_t o = ((size_t)col * ldl + row) * 2;
+      Lt[o] = re; Lt[o + 1] = im;
+    };
+    if (a < Kc) {
+      put(a, b, g0r, g0i);
+      put(Kc + a, Kc + b, g2r, g2i);
+      put(Kc + a, b, g1r, g1i);
+      if (a != b) put(Kc + b, a, g1r, -g1i);
+    } else {
+      // signal row: entry = sum ww s x_b = conj(rhs_b); the augmented row M holds conj(rhs)^T
+      put(M, b, g0r, g0i);
+      put(M, Kc + b, g1r, g1i);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase C: left-looking Cholesky on the transposed storage (coalesced over rows), RHS as row M, then
+// back substitution by wave 0.  Result x (M complex) in LDS `xs` (interleaved).
+__device__ void cholesky_solve(double* __restrict__ Lt, int M, int ldl, double* rowj, double* xs, double* sh) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = 0; j < M; ++j) {
+    // row j of L (entries k < j) -> LDS
+    for (int k = tid; k < j; k += nt) {
+      size_t o = ((size_t)k * ldl + j) * 2;
+      rowj[2 * k] = Lt[o];
+      rowj[2 * k + 1] = Lt[o + 1];
+    }
+    __syncthreads();
+    for (int i = j + tid; i <= M; i += nt) {
+      size_t oj = ((size_t)j * ldl + i) * 2;
+      double ar = Lt[oj], ai = Lt[oj + 1];
+      for (int k = 0; k < j; ++k) {
+        size_t o = ((size_t)k * ldl + i) * 2;
+        double lr = Lt[o], li = Lt[o + 1];
+        double cr = rowj[2 * k], ci = rowj[2 * k + 1];
+        ar -= lr * cr + li * ci;  // L[i][k] * conj(L[j][k])
+        ai -= li * cr - lr * ci;
+      }
+      if (i == j) {
+        double d = sqrt(ar);
+        sh[0] = d;
+        Lt[oj] = d; Lt[oj + 1] = 0.0;
+      } else {
+        Lt[oj] = ar; Lt[oj + 1] = ai;  // scaled below
+      }
+    }
+    __syncthreads();
+    double inv = 1.0 / sh[0];
+    for (int i = j + 1 + tid; i <= M; i += nt) {
+      size_t oj = ((size_t)j * ldl + i) * 2;
+      Lt[oj] *= inv; Lt[oj + 1] *= inv;
+    }
+    __syncthreads();
+  }
+  // back substitution: y_j = conj(L[M][j]); x_j = (y_j - sum_{i>j} conj(L[i][j]) x_i) / L[j][j]
+  if (tid < 64) {
+    for (int j = M - 1; j >= 0; --j) {
+      const double* row = Lt + (size_t)j * ldl * 2;
+      double sr = 0, si = 0;
+      for (int i = j + 1 + tid; i < M; i += 64) {
+        double lr = row[2 * i], li = row[2 * i + 1];
+        double xr = xs[2 * i], xi = xs[2 * i + 1];
+        sr += lr * xr + li * xi;  // conj(l) * x
+        si += lr * xi - li * xr;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o);
+        si += __shfl_xor(si, o);
+      }
+      if (tid == 0) {
+        double d = row[2 * j];
+        double yr = row[2 * M], yi = -row[2 * M + 1];
+        xs[2 * j] = (yr - sr) / d;
+        xs[2 * j + 1] = (yi - si) / d;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+  __syncthreads();
+}
+
+// numpy.blackman / numpy.hamming (symmetric form: n = 2u - (N-1))
+__device__ inline double window_value(int mode_blackman, int u, int N) {
+  double n = (double)(2 * u - (N - 1));
+  double den = (double)(N - 1);
+  if (mode_blackman) return 0.42 + 0.5 * cos(M_PI * n / den) + 0.08 * cos(2.0 * M_PI * n / den);
+  return 0.54 + 0.46 * cos(M_PI * n / den);
+}
+
+struct LsArgs {
+  int mode;  // 0: adaptation 0 (stationary harmonics), 1: adaptation >= 1 (tracks)
+  const double* s; long long L; double fs;
+  const double* am_cur; const double* fm_cur; int Kmax;
+  const int* frame_inst; const int* frame_c; const int* frame_wl; const double* frame_f0; const int* frame_K;
+  const int* ncol; const int* cols; const unsigned char* seeded; const int* any_seed;
+  int n_frames; int a_iter; double f0_stale; double f0min;
+  double* records; double* raw_amp; double* raw_slope;
+  double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
+};
+
+// seed-aware track access (functions.py:209-210; see eaqhm_frame_prep)
+__device__ inline double track_fm(const LsArgs& A, int k, long long t, int c, bool seeds) {
+  if (seeds && k == 0 && t <= c && A.seeded[t]) return 140.0;
+  return A.fm_cur[(size_t)k * A.L + t];
+}
+__device__ inline double track_am(const LsArgs& A, int k, long long t, int c, bool seeds) {
+  if (seeds && k == 0 && t <= c && A.seeded[t]) return 10e-4;
+  return A.am_cur[(size_t)k * A.L + t];
+}
+
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  LsScratch S = carve(A.scratch + (size_t)blockIdx.x * A.scratch_stride, A.nmax, A.Nmax, A.Kcmax);
+  const int Mmax = 2 * A.Kcmax;
+  double* ww = lds;                 // Nmax
+  double* rowj = ww + A.Nmax;       // 2*Mmax
+  double* xs = rowj + 2 * Mmax;     // 2*Mmax
+  double* rho = xs + 2 * Mmax;      // 2*nmax
+  double* sh = rho + 2 * A.nmax;    // 8
+  const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
+  const double eps = 10e-5;  // functions.py:517
+
+  for (int f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
+    const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
+    const int N = 2 * wl + 1, mid = wl;
+    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
+    const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc;
+    const int ldx = C1, ldl = M + 1;
+    const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
+    const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
+
+    // ---------------- Phase A ----------------
+    for (int u = tid; u < N; u += nt) {
+      double w = window_value(A.mode == 0, u, N);
+      ww[u] = w * w;
+      S.Xre[(size_t)u * ldx + n] = 1.0;   // DC column
+      S.Xim[(size_t)u * ldx + n] = 0.0;
+      S.Xre[(size_t)u * ldx + Kc] = A.s[(size_t)(c - wl) + u];  // signal column
+      S.Xim[(size_t)u * ldx + Kc] = 0.0;
+    }
+    if (A.mode == 1) {
+      // A1: one thread per active slot: gap fill, running sums from the middle outwards, ratios
+      for (int j = tid; j < n; j += nt) {
+        const int k = mycols[j];
+        const long long t0 = (long long)c - wl;
+        double* Qc = S.Q + j;  // element u+1 at Qc[(u+1)*n]
+        double* rc = S.r + j;  // element u   at rc[u*n]
+        int last = -1;
+        double ylo_f = 0, ylo_a = 0;
+        for (int u = 0; u < N; ++u) {
+          double v = track_fm(A, k, t0 + u, c, seeds);
+          if (v != 0.0) {
+            double va = track_am(A, k, t0 + u, c, seeds);
+            if (last < u - 1) {
+              if (last < 0) {  // leading gap: hold (functions.py:259-263)
+                for (int g = 0; g < u; ++g) { Qc[(size_t)(g + 1) * n] = v; rc[(size_t)g * n] = va; }
+              } else {         // interior gap: linear (functions.py:277-278)
+                double dx = (double)(u - last);
+                double sf = (v - ylo_f) / dx, sa = (va - ylo_a) / dx;
+                for (int g = last + 1; g < u; ++g) {
+                  double xx = (double)(g - last);
+                  Qc[(size_t)(g + 1) * n] = sf * xx + ylo_f;
+                  rc[(size_t)g * n] = sa * xx + ylo_a;
+                }
+              }
+            }
+            Qc[(size_t)(u + 1) * n] = v;
+            rc[(size_t)u * n] = va;
+            last = u; ylo_f = v; ylo_a = va;
+          }
+        }
+        for (int g = last + 1; g < N; ++g) {  // trailing gap: hold (functions.py:265-271)
+          Qc[(size_t)(g + 1) * n] = ylo_f; rc[(size_t)g * n] = ylo_a;
+        }
+        // running sums relative to the middle: Q[u] = sum_{v<=u} fm[v] - sum_{v<=mid} fm[v]
+        const double fmid = Qc[(size_t)(mid + 1) * n];
+        double acc = 0.0;
+        Qc[(size_t)(mid + 1) * n] = 0.0;
+        for (int u = mid + 1; u < N; ++u) {
+          acc += Qc[(size_t)(u + 1) * n];
+          Qc[(size_t)(u + 1) * n] = acc;
+        }
+        acc = 0.0;
+        double fnext = fmid;
+        for (int u = mid - 1; u >= -1; --u) {
+          double tmp = (u >= 0) ? Qc[(size_t)(u + 1) * n] : 0.0;
+          acc -= fnext;
+          Qc[(size_t)(u + 1) * n] = acc;
+          fnext = tmp;
+        }
+        const double amid = rc[(size_t)mid * n] + eps;
+        for (int u = 0; u < N; ++u) rc[(size_t)u * n] = (eps + rc[(size_t)u * n]) / amid;
+        double sn, cs;
+        sincos((2.0 * M_PI * fmid) / A.fs, &sn, &cs);
+        rho[2 * j] = cs; rho[2 * j + 1] = sn;
+      }
+      __syncthreads();
+      // A3: one sincos per (sample, positive column); it feeds the positive column at u and the
+      // negative column at N-2-u (time-reversed, functions.py:284-285)
+      const int items = (N + 1) * n;
+      for (int idx = tid; idx < items; idx += nt) {
+        int u = idx / n - 1, j = idx - (u + 1) * n;
+        double q = S.Q[(size_t)(u + 1) * n + j];
+        double sn, cs;
+        sincos((2.0 * M_PI * q) / A.fs, &sn, &cs);
+        if (u >= 0) {
+          double rr = S.r[(size_t)u * n + j];
+          S.Xre[(size_t)u * ldx + n + 1 + j] = rr * cs;
+          S.Xim[(size_t)u * ldx + n + 1 + j] = rr * sn;
+        }
+        if (u <= N - 2) {
+          int t = N - 2 - u;
+          double rr = S.r[(size_t)(u + 1) * n + j];
+          double pr = rho[2 * j], pi = rho[2 * j + 1];
+          S.Xre[(size_t)t * ldx + j] = rr * (cs * pr - sn * pi);
+          S.Xim[(size_t)t * ldx + j] = rr * (cs * pi + sn * pr);
+        }
+      }
+    } else {
+      // adaptation 0: E0[n,k] = exp(j*2*pi*k*f0*n/fs) (functions.py:453-454); negative = conjugate
+      const int items = N * n;
+      for (int idx = tid; idx < items; idx += nt) {
+        int u = idx / n, j = idx - u * n;
+        double fk = (double)(j + 1) * f0;
+        double nn = (double)(u - mid);
+        double sn, cs;
+        sincos((nn * 2.0 * M_PI * fk) / A.fs, &sn, &cs);
+        S.Xre[(size_t)u * ldx + n + 1 + j] = cs;
+        S.Xim[(size_t)u * ldx + n + 1 + j] = sn;
+        S.Xre[(size_t)u * ldx + j] = cs;
+        S.Xim[(size_t)u * ldx + j] = -sn;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- Phase B / C ----------------
+    gram_to_system(S.Xre, S.Xim, N, Kc, ldx, ww, (double)mid, S.Lt, ldl);
+    __syncthreads();
+    cholesky_solve(S.Lt, M, ldl, rowj, xs, sh);
+
+    // ---------------- Phase D ----------------
+    if (A.raw_amp) {
+      const int stride = 2 * (2 * A.Kmax + 1);
+      for (int q = tid; q < 2 * Kc; q += nt) {
+        A.raw_amp[(size_t)f * stride + q] = xs[q];
+        A.raw_slope[(size_t)f * stride + q] = xs[2 * Kc + q];
+      }
+    }
+    // amplitude floor over the positive slots (functions.py:309)
+    double amax = 0.0;
+    for (int j = tid; j < n; j += nt) {
+      double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
+      amax = fmax(amax, hypot(ar, ai));
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) sh[1 + (tid >> 6)] = amax;
+    __syncthreads();
+    amax = fmax(fmax(sh[1], sh[2]), fmax(sh[3], sh[4]));
+    const double floor_db = 20.0 * log10(amax) - 150.0;
+    const double h = f0 / (double)(A.a_iter + 1);  // functions.py:310
+    double* rec = A.records + (size_t)inst * (3 * A.Kmax + 1);
+    for (int k = tid; k < 3 * A.Kmax; k += nt) rec[k] = 0.0;
+    __syncthreads();
+    for (int j = tid; j < n; j += nt) {
+      const int k = (A.mode == 0) ? j : mycols[j];
+      double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
+      double br = xs[2 * (Kc + n + 1 + j)], bi = xs[2 * (Kc + n + 1 + j) + 1];
+      double mag = hypot(ar, ai);
+      double eta = 0.0;
+      if (A.mode == 1) eta = A.fs / (2.0 * M_PI) * ((ar * bi - ai * br) / (mag * mag));  // functions.py:297
+      if (20.0 * log10(mag) > floor_db && fabs(eta) < h) {
+        rec[k] = mag;
+        rec[2 * A.Kmax + k] = atan2(ai, ar);
+        double fmv;
+        if (A.mode == 0) fmv = (double)(k + 1) * f0;
+        else {
+          double cur = track_fm(A, k, c, c, seeds);
+          fmv = (f0 > A.f0min) ? cur + eta : cur;
+        }
+        rec[A.Kmax + k] = fmv;
+      }
+    }
+    if (tid == 0) rec[3 * A.Kmax] = xs[2 * n];  // Re(a_DC) (functions.py:303)
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptation >= 1 frame set-up (functions.py:202-213): active slots + empty-row seeding flags
+extern "C" __global__ void eaqhm_frame_prep_kernel(const double* fm_cur, long long L, int Kmax, const int* frame_c,
+                                                   int n_frames, int* ncol, int* cols, unsigned char* seeded,
+                                                   int* any_seed) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  int c = frame_c[f], n = 0;
+  for (int k = 0; k < Kmax; ++k)
+    if (fm_cur[(size_t)k * L + c] != 0.0) cols[(size_t)f * Kmax + n++] = k;
+  if (n == 0) {
+    seeded[c] = 1;
+    cols[(size_t)f * Kmax] = 0;
+    n = 1;
+    atomicOr(any_seed, 1);
+  }
+  ncol[f] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// explicit-matrix seam (one frame): eaqhmLS_complexamps / iqhmLS_complexamps as Python-level functions
+struct LsExplicitArgs {
+  const double* s; int N; const double* am; const double* fm; const double* f0range; int Kc;
+  const double* window; double fs; double* out_amp; double* out_slope; double* scratch;
+};
+
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_explicit_kernel(LsExplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = A.N, Kc = A.Kc, C1 = Kc + 1, M = 2 * Kc, ldx = C1, ldl = M + 1;
+  double* Xre = A.scratch;
+  double* Xim = Xre + (size_t)N * C1;
+  double* Lt = Xim + (size_t)N * C1;
+  double* ww = lds;
+  double* rowj = ww + N;
+  double* xs = rowj + 2 * M;
+  double* sh = xs + 2 * M;
+  const double eps = 10e-5;
+  const bool eaqhm_mode = (A.fm != nullptr);
+  // functions.py:446 / :503: midlen = (len-1)/2 (float) for iqhm, int((len-1)/2) for eaqhm
+  const double midf = eaqhm_mode ? (double)((N - 1) / 2) : 0.5 * (double)(N - 1);
+  const int midi = (N - 1) / 2;
+  for (int u = tid; u < N; u += nt) {
+    double w = A.window[u];
+    ww[u] = w * w;
+    Xre[(size_t)u * ldx + Kc] = A.s[u];
+    Xim[(size_t)u * ldx + Kc] = 0.0;
+  }
+  for (int j = tid; j < Kc; j += nt) {
+    if (eaqhm_mode) {
+      double fan_mid = 0.0, acc = 0.0;
+      for (int u = 0; u <= midi; ++u) acc += A.fm[(size_t)u * Kc + j];
+      fan_mid = acc;
+      const double amid = A.am[(size_t)midi * Kc + j] + eps;
+      acc = 0.0;
+      for (int u = 0; u < N; ++u) {
+        acc += A.fm[(size_t)u * Kc + j];  // lfilter([1],[1,-1]) == running sum (functions.py:510)
+        double sn, cs;
+        sincos((2.0 * M_PI * (acc - fan_mid)) / A.fs, &sn, &cs);
+        double rr = (eps + A.am[(size_t)u * Kc + j]) / amid;
+        Xre[(size_t)u * ldx + j] = rr * cs;
+        Xim[(size_t)u * ldx + j] = rr * sn;
+      }
+    } else {
+      const double fk = A.f0range[j];
+      for (int u = 0; u < N; ++u) {
+        double nn = (double)u - midf;
+        double sn, cs;
+        sincos((nn * 2.0 * M_PI * fk) / A.fs, &sn, &cs);
+        Xre[(size_t)u * ldx + j] = cs;
+        Xim[(size_t)u * ldx + j] = sn;
+      }
+    }
+  }
+  __syncthreads();
+  gram_to_system(Xre, Xim, N, Kc, ldx, ww, midf, Lt, ldl);
+  __syncthreads();
+  cholesky_solve(Lt, M, ldl, rowj, xs, sh);
+  for (int q = tid; q < 2 * Kc; q += nt) {
+    A.out_amp[q] = xs[q];
+    A.out_slope[q] = xs[2 * Kc + q];
+  }
+}
+
+}  // namespace eaqhm
+
+// ================================================================================================
+// C ABI
+using namespace eaqhm;
+
+extern "C" int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int32_t Kmax,
+                                const int32_t* frame_c, int32_t n_frames, int32_t* ncol, int32_t* cols,
+                                uint8_t* seeded, int32_t* any_seed) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (!fm_cur || !frame_c || !ncol || !cols || !seeded || !any_seed || L <= 0 || Kmax <= 0 || n_frames < 0)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_frame_prep: bad argument");
+  HIP_TRY(ctx, hipMemsetAsync(seeded, 0, (size_t)L, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(any_seed, 0, sizeof(int32_t), ctx->stream));
+  if (n_frames == 0) return EAQHM_OK;
+  hipLaunchKernelGGL(eaqhm_frame_prep_kernel, dim3((n_frames + 127) / 128), dim3(128), 0, ctx->stream, fm_cur,
+                     (long long)L, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int64_t L, double fs,
+                              const double* am_cur, const double* fm_cur, int32_t Kmax, const int32_t* frame_inst,
+                              const int32_t* frame_c, const int32_t* frame_wl, const double* frame_f0,
+                              const int32_t* frame_K, const int32_t* ncol, const int32_t* cols,
+                              const uint8_t* seeded, const int32_t* any_seed, int32_t n_frames, int32_t wl_max,
+                              int32_t a_iter, double f0_stale, double f0min, double* records, double* raw_amp,
+                              double* raw_slope) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (mode != 0 && mode != 1) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: mode must be 0 or 1");
+  if (!s || L <= 0 || fs <= 0 || Kmax <= 0 || !frame_inst || !frame_c || !frame_wl || !records ||
+      n_frames < 0)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: bad argument");
+  if (mode == 0 && (!frame_f0 || !frame_K)) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: mode 0 needs frame_f0/frame_K");
+  if (mode == 1 && (!am_cur || !fm_cur || !ncol || !cols || !seeded || !any_seed))
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: mode 1 needs tracks and eaqhm_frame_prep outputs");
+  if ((raw_amp == nullptr) != (raw_slope == nullptr)) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: raw_amp/raw_slope");
+  if (n_frames == 0) return EAQHM_OK;
+  if (wl_max <= 0) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: wl_max must be positive");
+  const int nmax = Kmax, Nmax = 2 * wl_max + 1, Kcmax = 2 * Kmax + 1;
+  const size_t stride = (ls_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
+  int grid = ctx->n_cu * 2;
+  if (grid > n_frames) grid = n_frames;
+  int rc = ctx->reserve(stride * grid * sizeof(double));
+  if (rc) return rc;
+  LsArgs A;
+  A.mode = mode; A.s = s; A.L = L; A.fs = fs; A.am_cur = am_cur; A.fm_cur = fm_cur; A.Kmax = Kmax;
+  A.frame_inst = frame_inst; A.frame_c = frame_c; A.frame_wl = frame_wl; A.frame_f0 = frame_f0; A.frame_K = frame_K;
+  A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
+  A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
+  A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
+  A.Kcmax = Kcmax;
+  size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
+  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(eaqhm_ls_kernel, dim3(grid), dim3(256), lds_bytes, ctx->stream, A);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_ls_explicit(eaqhm_ctx* ctx, const double* s, int32_t N, const double* am, const double* fm,
+                                 const double* f0range, int32_t Kc, const double* window, double fs, double* out_amp,
+                                 double* out_slope) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (!s || N < 2 || Kc < 1 || !window || fs <= 0 || !out_amp || !out_slope)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: bad argument");
+  if (fm) {
+    if (!am) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: fm given without am");
+    if ((N & 1) == 0) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: eaqhm seam needs an odd window length");
+  } else if (!f0range) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: need fm or f0range");
+  const size_t C1 = (size_t)Kc + 1, M = 2 * (size_t)Kc;
+  size_t doubles = 2 * (size_t)N * C1 + 2 * M * (M + 1);
+  int rc = ctx->reserve(doubles * sizeof(double));
+  if (rc) return rc;
+  LsExplicitArgs A{s, N, am, fm, f0range, Kc, window, fs, out_amp, out_slope, (double*)ctx->scratch};
+  size_t lds_bytes = ((size_t)N + 4 * M + 8) * sizeof(double);
+  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: problem too large");
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_explicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(eaqhm_ls_explicit_kernel, dim3(1), dim3(256), lds_bytes, ctx->stream, A);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}

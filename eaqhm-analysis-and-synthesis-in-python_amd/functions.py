@@ -1,0 +1,160 @@
+"""Drop-in replacement for the reference's functions.py entry points, backed by libeaqhm_hip.so.
+
+    eaQHMAnalysisAndSynthesis(speechFile, gender='other', step=15, maxAdpt=10, pitchPeriods=3,
+                              analysisWindow=32, fullWaveform=True, fc=0, partials=0,
+                              printPrompts=True, loadingScreen=True)
+        -> (s_recon, SRER, DetComponents, endTime)                      [functions.py:35-418]
+    iqhmLS_complexamps(s, f0range, window, fs)   -> (amplitudes, slopes) [functions.py:420-470]
+    eaqhmLS_complexamps(s, am, fm, window, fs)   -> (amplitudes, slopes) [functions.py:472-535]
+
+Same names, argument meaning, defaults, return shapes and error behaviour (Python exceptions).
+There is no CPU path: without the HIP library or a GPU every call raises `HipUnavailable`.
+"""
+from time import gmtime, strftime, time
+
+import numpy as np
+
+from . import prologue
+from .engine import DeviceAnalysis, FramePlan
+from .hip import Context
+from .structs import Deterministic
+
+_seam_ctx = {}
+
+
+def _ctx(device_index=0):
+    c = _seam_ctx.get(device_index)
+    if c is None:
+        c = _seam_ctx[device_index] = Context(device_index)
+    c.bind_stream()
+    return c
+
+
+def _slot_array(slots, values):
+    """What misc.py:65-93 (arrayByIndex) returns when it is fed the (n,1)-shaped index and value
+    arrays of functions.py:407-411: an object array of length max(slot)+1 whose active entries are
+    shape-(1,) float64 arrays and whose other entries are the int 0."""
+    if len(slots) == 0:
+        # the reference raises IndexError here (end() of an empty array); an empty array is kinder
+        return np.zeros(0, dtype=object)
+    out = np.zeros(int(slots[-1]) + 1, dtype=object)
+    for k, v in zip(slots, values):
+        out[int(k)] = np.array([v], dtype=np.float64)
+    return out
+
+
+def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', step: int = 15,
+                              maxAdpt: int = 10, pitchPeriods: int = 3, analysisWindow: int = 32,
+                              fullWaveform: bool = True, fc: int = 0, partials: int = 0,
+                              printPrompts: bool = True, loadingScreen: bool = True, *,
+                              pitch_track=None, device_index: int = 0, _return_engine: bool = False):
+    """Adaptive quasi-harmonic analysis/resynthesis of a mono 16-bit .wav on an MI355X.
+
+    Parameters and returns: exactly those of the reference (functions.py:38-82).  `loadingScreen` is
+    accepted and ignored (there is no per-frame Python loop to show progress for).
+
+    Keyword-only extensions (not in the reference):
+      pitch_track   (T, >=2) array [time s, f0 Hz, ...] used instead of running SWIPE' — either the
+                    1 ms track swipep() returns or an already resampled 5 ms grid
+      device_index  which GPU of this process to use
+    """
+    start = time()
+    fs, s = prologue.read_signal(speechFile, fc)                                 # functions.py:86-91
+    length = len(s)
+    f0min, f0max = prologue.pitch_limits(gender)                                 # functions.py:95-109
+    if pitch_track is None:
+        from .swipe import swipep
+        pitch_track = swipep(s, fs, [f0min, f0max])                              # functions.py:111
+    grid_t = np.arange(0, length - 1, round(fs * 5 / 1000)) / fs
+    f0_grid = prologue.resample_track(pitch_track, grid_t)                       # functions.py:113
+    frames, frame_step = prologue.voiced_unvoiced_frames(s, fs, gender)          # functions.py:125
+    if fullWaveform:
+        prologue.apply_full_waveform(frames, length, analysisWindow * step)      # functions.py:139-146
+        target = s
+    else:
+        target = prologue.voiced_only_target(s, frames, frame_step)              # functions.py:127-138
+    plan = FramePlan(length, fs, f0_grid, frames, frame_step, step, pitchPeriods, analysisWindow, partials)
+    eng = DeviceAnalysis(s, target, plan, f0min, maxAdpt, device_index=device_index)
+
+    state = {"t": time()}
+
+    def report(a, e):
+        if printPrompts:                                                         # functions.py:390-392
+            print('---- Adaptation No. {} ----\n'.format(a))
+            print('\nSRER: {} dB in Adaptation No: {}'.format(e.SRER[a], a))
+            print('Adaptation Time: {}\n'.format(strftime("%H:%M:%S", gmtime(time() - state["t"]))))
+        state["t"] = time()
+
+    eng.run(on_adaptation=report)
+    fin = eng.final_arrays()
+    det = pack_results(plan, fin)
+    end_time = time() - start
+    if printPrompts:                                                             # functions.py:414-416
+        print('Signal adapted to {} dB SRER'.format(round(max(eng.SRER), 6)))
+        print('Total Time: {}\n\n'.format(strftime("%H:%M:%S", gmtime(end_time))))
+    out = (fin["s_recon"], list(eng.SRER), det, end_time)
+    return out + (eng,) if _return_engine else out
+
+
+def pack_results(plan, fin):
+    """functions.py:325-329 + :404-411: one Deterministic per analysis instant."""
+    det = []
+    centres = plan.ti - 1
+    for i in range(plan.No_ti):
+        ti = np.int64(centres[i])
+        if plan.analysed[i]:
+            d = Deterministic(ti=ti, isSpeech=True, isVoiced=True)
+            nz = np.flatnonzero(fin["am"][i])
+            d.a0 = np.float64(fin["a0"][i])
+            d.amplitudes = _slot_array(nz, fin["am"][i, nz])
+            d.frange = _slot_array(nz, fin["fm"][i, nz])
+            d.pk = _slot_array(nz, fin["pk"][i, nz])
+        elif plan.in_bounds[i]:
+            d = Deterministic(ti=ti, isSpeech=True, isVoiced=False)
+        else:
+            d = Deterministic(ti=ti, isSpeech=False, isVoiced=False)
+        det.append(d)
+    return det
+
+
+def _column(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+
+def _ls_explicit(s, am, fm, f0range, window, fs):
+    import torch
+    c = _ctx()
+    dev = c.device
+    s = _column(s)
+    N = len(s)
+    window = _column(window)
+    if len(window) != N:
+        raise ValueError("window and signal lengths differ")
+
+    def up(a):
+        return None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+
+    if fm is not None:
+        am, fm = np.asarray(am, dtype=np.float64), np.asarray(fm, dtype=np.float64)
+        if fm.shape != am.shape or fm.shape[0] != N:
+            raise ValueError("am/fm must both be (len(s), K)")
+        Kc = fm.shape[1]
+    else:
+        f0range = _column(f0range)
+        Kc = len(f0range)
+    out_a = torch.zeros(2 * Kc, dtype=torch.float64, device=dev)
+    out_b = torch.zeros(2 * Kc, dtype=torch.float64, device=dev)
+    c.ls_explicit(up(s), N, up(am), up(fm), up(f0range), Kc, up(window), fs, out_a, out_b)
+    a = out_a.cpu().numpy().view(np.complex128).reshape(Kc, 1)
+    b = out_b.cpu().numpy().view(np.complex128).reshape(Kc, 1)
+    return a, b
+
+
+def iqhmLS_complexamps(s, f0range, window, fs: int):
+    """functions.py:420-470 on the GPU: returns (amplitudes, slopes), each (K, 1) complex128."""
+    return _ls_explicit(s, None, None, f0range, window, fs)
+
+
+def eaqhmLS_complexamps(s, am, fm, window, fs):
+    """functions.py:472-535 on the GPU: returns (amplitudes, slopes), each (K, 1) complex128."""
+    return _ls_explicit(s, am, fm, None, window, fs)

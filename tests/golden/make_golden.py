@@ -36,12 +36,17 @@ np.NAN = np.nan
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 sys.path.insert(0, REF)
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "eaqhm-analysis-and-synthesis-in-python_amd"))
 
 import functions as F  # noqa: E402  (the reference)
 from scipy.io import wavfile  # noqa: E402
 
-from synth import synth_speech_int16  # noqa: E402  (our own generator, shared with bench.py)
+import importlib.util  # noqa: E402
+
+_sp = importlib.util.spec_from_file_location(
+    "eaqhm_synth", os.path.join(os.path.dirname(os.path.dirname(HERE)), "eaqhm-analysis-and-synthesis-in-python_amd", "synth.py"))
+_synth = importlib.util.module_from_spec(_sp)
+_sp.loader.exec_module(_synth)          # our own generator, shared with bench.py (never the reference's)
+synth_speech_int16 = _synth.synth_speech_int16
 
 
 # --------------------------------------------------------------------------- capture machinery
@@ -369,7 +374,7 @@ def job_units():
     o["pii_fm"], o["pii_ph"], o["pii_knots"] = fm, ph, knots
     o["pii_out"] = F.phase_integr_interpolation(fm.copy(), ph.copy(), knots)
     # iqhm / eaqhm on small random problems
-    N, K = 61, 3
+    N, K = 241, 6     # 3 pitch periods at 210 Hz: cond(R) ~ 1e3 like the real frames
     f0 = 210.0
     f0range = np.arange(-K, K + 1) * f0
     w = np.blackman(N)

@@ -1,0 +1,248 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Everything goes through the C ABI of
+libeaqhm_hip.so via the package's ctypes layer; the checker is the oracle and the golden vectors the
+reference itself produced (tests/golden/make_golden.py).
+
+Stated tolerances (SURVEY.md §8c, FP64 path): amplitudes <= 1e-8 * max, frequencies <= 1e-3 Hz,
+phases <= 1e-5 rad (mod 2*pi), identical acceptance mask on >= 99.9 % of the cells,
+SRER <= 1e-6 dB per adaptation (north-star bar: 0.1 dB).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, unpack_records
+
+pytestmark = pytest.mark.gpu
+
+TOL_AM_REL, TOL_FM_HZ, TOL_PH_RAD, TOL_SRER_DB = 1e-8, 1e-3, 1e-5, 1e-6
+
+
+def wrap(d):
+    return (d + np.pi) % (2 * np.pi) - np.pi
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import eaqhm_amd
+    return eaqhm_amd
+
+
+def relerr(a, b):
+    return np.abs(np.asarray(a).ravel() - np.asarray(b).ravel()).max() / np.abs(np.asarray(b)).max()
+
+
+# ----------------------------------------------------------------------------- LS seams
+def test_ls_seams_unit_vectors(amd):
+    u = load_golden("unit_vectors.npz")
+    a, b = amd.iqhmLS_complexamps(u["iq_s"].reshape(-1, 1), u["iq_f0range"], u["iq_w"], 16000)
+    assert a.shape == (len(u["iq_f0range"]), 1) and a.dtype == np.complex128
+    assert relerr(a, u["iq_amp"]) < 1e-10 and relerr(b, u["iq_slope"]) < 1e-10
+    a, b = amd.eaqhmLS_complexamps(u["ea_s"].reshape(-1, 1), u["ea_am"], u["ea_fm"], u["ea_w"], 16000)
+    assert relerr(a, u["ea_amp"]) < 1e-10 and relerr(b, u["ea_slope"]) < 1e-10
+
+
+def test_ls_seams_sa19_frames(amd, sa19_golden):
+    g = sa19_golden
+    for idx in (0, 700, 2000, 3500):
+        p = "iqhm%d_" % idx
+        a, b = amd.iqhmLS_complexamps(g[p + "s"], g[p + "f0range"], g[p + "window"], int(g[p + "fs"]))
+        assert relerr(a, g[p + "amp"]) < 1e-9 and relerr(b, g[p + "slope"]) < 1e-9
+        p = "eaqhm%d_" % idx
+        a, b = amd.eaqhmLS_complexamps(g[p + "s"], g[p + "am"], g[p + "fm"], g[p + "window"], int(g[p + "fs"]))
+        assert relerr(a, g[p + "amp"]) < 1e-8 and relerr(b, g[p + "slope"]) < 1e-8
+
+
+def test_ls_seam_errors(amd):
+    with pytest.raises(ValueError):
+        amd.iqhmLS_complexamps(np.zeros(11), np.arange(3.0), np.ones(10), 16000)
+    with pytest.raises(RuntimeError):     # even window length: the reference's eaqhm seam breaks too
+        amd.eaqhmLS_complexamps(np.zeros(10), np.ones((10, 3)), np.ones((10, 3)), np.ones(10), 16000)
+
+
+# ----------------------------------------------------------------------------- full SA19 run
+@pytest.fixture(scope="module")
+def sa19_run(amd, sa19_golden):
+    g = sa19_golden
+    seen = {}
+
+    from eaqhm_amd import functions as F
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    eng = DeviceAnalysis(s, s, plan, 160, 10)
+
+    def hook(a, e):
+        rec = e.records[0][:e.plan.No_ti].cpu().numpy()
+        K = e.plan.Kmax
+        seen[a] = dict(am=rec[:, :K].copy(), fm=rec[:, K:2 * K].copy(), ph=rec[:, 2 * K:3 * K].copy(),
+                       a0=rec[:, 3 * K].copy(), s_hat=e.s_hat[0].cpu().numpy(),
+                       ph_knot=e.ph_knot[0].cpu().numpy())
+        if a == 0:
+            seen["dense0"] = dict(am=e.am_cur.cpu().numpy(), fmcur=e.fm_cur.cpu().numpy())
+
+    eng.run(on_adaptation=hook)
+    fin = eng.final_arrays()
+    det = F.pack_results(plan, fin)
+    return dict(eng=eng, plan=plan, seen=seen, fin=fin, det=det)
+
+
+def test_sa19_plan(sa19_run, sa19_golden):
+    p, g = sa19_run["plan"], sa19_golden
+    assert p.Kmax == 59 and p.No_ti == 4233 and p.n_frames == 4169
+    assert np.array_equal(p.ti[p.analysed], g["ti_a0"])
+    assert np.abs(p.frame_f0 - g["f0_a0"]).max() == 0
+    assert abs(p.f0_stale - g["stale_f0"][0, 1]) == 0
+    sh = g["ls_shapes_iqhm"]
+    assert np.array_equal(2 * p.frame_wl + 1, sh[:, 0]) and np.array_equal(2 * p.frame_K + 1, sh[:, 1])
+
+
+def test_sa19_srer(sa19_run, sa19_golden):
+    srer = np.array(sa19_run["eng"].SRER)
+    assert len(srer) == 6
+    assert np.abs(srer - sa19_golden["SRER"]).max() < TOL_SRER_DB
+    assert sa19_run["eng"].n_ls_frames == 6 * 4169
+
+
+@pytest.mark.parametrize("a", [0, 1])
+def test_sa19_records(sa19_run, sa19_golden, a):
+    """Frame-centre records of adaptations 0 (iQHM) and 1 (eaQHM) against the reference's."""
+    got = sa19_run["seen"][a]
+    ref = unpack_records(sa19_golden, a, with_fm=(a > 0))
+    mask = got["am"] != 0
+    agree = np.mean(mask == ref["mask"])
+    assert agree >= 0.999, "acceptance mask agreement %.6f" % agree
+    both = mask & ref["mask"]
+    assert np.abs(got["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(wrap(got["ph"][both] - ref["ph"][both])).max() <= TOL_PH_RAD
+    assert np.abs(got["a0"] - ref["a0"]).max() <= TOL_AM_REL
+    if a > 0:
+        assert np.abs(got["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
+
+
+def test_sa19_checksums_every_adaptation(sa19_run, sa19_golden):
+    for a in range(6):
+        got, gs = sa19_run["seen"][a], sa19_golden["recsum%d" % a]
+        assert abs(np.count_nonzero(got["am"]) - int(gs[0])) <= 2
+        assert abs(got["am"].sum() - gs[1]) <= 1e-7 * abs(gs[1])
+        assert abs(got["fm"].sum() - gs[2]) <= 1e-7 * abs(gs[2])
+        assert abs(got["a0"].sum() - gs[4]) <= 1e-7
+
+
+def test_sa19_dense_after_adaptation0(sa19_run, sa19_golden):
+    """Interpolation stage: dense am / next-iteration fm of slots 0, 30, 45, a0 and the synthesis."""
+    g, d = sa19_golden, sa19_run["seen"]["dense0"]
+    for k in (0, 30, 45):
+        for lo in (0, 30000):
+            p = "dense0_k%d_%d_" % (k, lo)
+            n = len(g[p + "am"])
+            assert np.abs(d["am"][k, lo:lo + n] - g[p + "am"]).max() <= TOL_AM_REL
+            assert np.abs(d["fmcur"][k, lo:lo + n] - g[p + "fmcur"]).max() <= TOL_FM_HZ
+    assert np.abs(sa19_run["seen"][0]["s_hat"] - g["dense0_srecon"]).max() <= 1e-9
+
+
+def test_sa19_returned_structs(sa19_run, sa19_golden):
+    g, det, fin = sa19_golden, sa19_run["det"], sa19_run["fin"]
+    assert len(det) == 4233
+    assert np.array_equal([d.ti for d in det], g["det_ti"])
+    assert np.array_equal([d.isSpeech for d in det], g["det_isSpeech"])
+    assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
+    assert np.abs(fin["s_recon"] - g["s_recon"]).max() <= 1e-9
+    v = g["det_isVoiced"]
+    assert np.abs(np.array([float(d.a0) for d in np.array(det, dtype=object)[v]]) - g["det_a0"][v]).max() <= TOL_AM_REL
+    cells = g["det_cells"]
+    i, k = cells[:, 0], cells[:, 1]
+    ref_mask = np.zeros_like(fin["am"], dtype=bool)
+    ref_mask[i, k] = True
+    assert np.mean((fin["am"] != 0) == ref_mask) >= 0.999
+    ok = fin["am"][i, k] != 0
+    assert np.abs(fin["am"][i, k][ok] - g["det_am"][ok]).max() <= TOL_AM_REL * g["det_am"].max()
+    assert np.abs(fin["fm"][i, k][ok] - g["det_fm"][ok]).max() <= TOL_FM_HZ
+    assert np.abs(wrap(fin["pk"][i, k][ok] - g["det_pk"][ok])).max() <= TOL_PH_RAD
+    # Python-level shape quirks of the structs
+    d = next(x for x in det if x.isVoiced)
+    q = g["det_quirk"]
+    assert type(d.ti).__name__ == q[0] and type(d.a0).__name__ == q[1] and str(d.amplitudes.dtype) == q[2]
+    assert type(d.amplitudes[0]).__name__ in ("ndarray", "int") and d.ak == []
+    first = next(e for e in d.amplitudes if isinstance(e, np.ndarray))
+    assert first.shape == (1,)
+    lens = g["det_len"]
+    assert np.array_equal([len(x.amplitudes) if x.isVoiced else 0 for x in det], lens)
+
+
+# ----------------------------------------------------------------------------- public entry point
+def test_entry_point_signature_and_synth16k(amd):
+    """eaQHMAnalysisAndSynthesis end to end on the 2 s synthetic 16 kHz signal, against the reference's
+    own output for it (golden) — exercises the stop rule (adaptation 3 is rejected)."""
+    import inspect
+    from scipy.io import wavfile
+    sig = inspect.signature(amd.eaQHMAnalysisAndSynthesis)
+    names = list(sig.parameters)[:11]
+    assert names == ["speechFile", "gender", "step", "maxAdpt", "pitchPeriods", "analysisWindow", "fullWaveform",
+                     "fc", "partials", "printPrompts", "loadingScreen"]
+    assert [sig.parameters[n].default for n in names[1:]] == ['other', 15, 10, 3, 32, True, 0, 0, True, True]
+    g = load_golden("synth16k_2s_adpt3.npz")
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "eaqhm_synth16k.wav")
+    wavfile.write(path, 16000, g["wav_int16"])
+    s_recon, SRER, det, T = amd.eaQHMAnalysisAndSynthesis(path, "female", maxAdpt=3, printPrompts=False,
+                                                         loadingScreen=False, pitch_track=g["swipe_track"])
+    assert isinstance(SRER, list) and len(SRER) == 4 and isinstance(T, float)
+    assert np.abs(np.array(SRER) - g["SRER"]).max() < TOL_SRER_DB
+    assert s_recon.shape == g["s_recon"].shape and np.abs(s_recon - g["s_recon"]).max() <= 1e-9
+    assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
+
+
+def test_voiced_only_option(amd):
+    """fullWaveform=False (functions.py:127-138) against the reference's run."""
+    g = load_golden("sa19_female_voicedonly_adpt1.npz")
+    s_recon, SRER, det, _ = amd.eaQHMAnalysisAndSynthesis(os.path.join(GOLDEN, "SA19.WAV"), "female", maxAdpt=1,
+                                                         fullWaveform=False, printPrompts=False,
+                                                         pitch_track=g["swipe_track"])
+    assert np.abs(np.array(SRER) - g["SRER"]).max() < TOL_SRER_DB
+    assert np.array_equal([d.isSpeech for d in det], g["det_isSpeech"])
+    assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
+    assert np.abs(s_recon - g["s_recon"]).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------- against the oracle
+@pytest.mark.parametrize("params", [dict(step=15, pitchPeriods=3, analysisWindow=32, partials=0),
+                                    dict(step=10, pitchPeriods=4, analysisWindow=50, partials=20)])
+def test_against_oracle_seeded_signal(amd, params):
+    """Same seeded synthetic input through the HIP path and the oracle, non-default parameters too."""
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.synth import synth_speech_int16
+    fs = 16000
+    s = synth_speech_int16(0.9, fs) / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    track = np.column_stack([t, f0, np.ones_like(t)])
+    grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    ti5 = np.array([f.ti for f in frames])
+    sp = np.array([float(f.isSpeech) for f in frames])
+    vo = np.array([float(f.isVoiced) for f in frames])
+    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=160, maxAdpt=2, step=params["step"],
+                    pitchPeriods=params["pitchPeriods"], analysisWindow=params["analysisWindow"],
+                    partials=params["partials"])
+    prologue.apply_full_waveform(frames, len(s), params["analysisWindow"] * params["step"])
+    plan = FramePlan(len(s), fs, grid, frames, fstep, params["step"], params["pitchPeriods"],
+                     params["analysisWindow"], params["partials"])
+    eng = DeviceAnalysis(s, s, plan, 160, 2)
+    eng.run()
+    fin = eng.final_arrays()
+    assert np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9
+    m = ref["am"] != 0
+    assert np.mean((fin["am"] != 0) == m) >= 0.999
+    both = m & (fin["am"] != 0)
+    assert np.abs(fin["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
+    assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= TOL_PH_RAD
