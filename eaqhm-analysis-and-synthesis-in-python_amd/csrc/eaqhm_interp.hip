@@ -1,9 +1,10 @@
 // eaqhm_interp.hip — track interpolation, phase integration, additive synthesis and SRER.
 // gfx950 (MI355X) only, FP64.
 //
-//   eaqhm_spline_kernel   one thread per harmonic slot (+1 for a0) walks the instants: runs of
-//                         consecutive accepted instants (functions.py:350-362) and the not-a-knot cubic
-//                         systems on their knots (functions.py:340, :367; interp1d(kind=3)).
+//   eaqhm_spline_kernel   one thread per (instant, slot): runs of consecutive accepted instants
+//                         (functions.py:350-362) and the not-a-knot cubic second derivatives on their knots
+//                         (functions.py:340, :367; interp1d(kind=3)) through the closed-form inverse of the
+//                         (1,4,1) system — a local 69-term sum instead of a sequential tridiagonal sweep.
 //   eaqhm_eval_kernel     one thread per sample, loop over slots: linear am (functions.py:364), cubic fm
 //                         (:367-371 incl. the padded <4-knot case), phase by frequency integration with the
 //                         sine-bump correction (functions.py:537-575), next-iteration frequency from the
@@ -20,75 +21,98 @@
 namespace eaqhm {
 
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void eaqhm_spline_kernel(const double* __restrict__ records,
-                                               int No_ti, int Kmax, int step, unsigned char* __restrict__ code,
-                                               double* __restrict__ mom, double* __restrict__ work) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > Kmax) return;
-  const int ld = Kmax + 1, RS = 3 * Kmax + 1;
-  const double h2 = (double)step * (double)step;
-  double* cp = work;                       // [No_ti][ld]
-  double* dp = work + (size_t)No_ti * ld;  // [No_ti][ld]
-  auto Y = [&](int i) -> double {
-    return (k == Kmax) ? records[(size_t)i * RS + 3 * Kmax] : records[(size_t)i * RS + Kmax + k];
-  };
-  auto ACC = [&](int i) -> bool { return (k == Kmax) ? true : (records[(size_t)i * RS + k] != 0.0); };
-  auto D2 = [&](int i) -> double { return 6.0 * ((Y(i - 1) - 2.0 * Y(i)) + Y(i + 1)) / h2; };
+// Not-a-knot cubic spline moments on uniformly spaced knots, one thread per (instant, slot).
+//
+// For a run of m >= 4 knots the second derivatives satisfy 6*M_1 = d_1, 6*M_{m-2} = d_{m-2},
+// M_0 = 2*M_1 - M_2, M_{m-1} = 2*M_{m-2} - M_{m-3}, and for the n = m-4 inner knots the (1,4,1) Toeplitz
+// system T x = dt with dt = d (minus M_1 / M_{m-2} in its first / last row).  T^-1 is known in closed form:
+//   (T^-1)_{ij} = (-1)^(i+j) lam^(|i-j|+1) (1-lam^(2 min(i,j))) (1-lam^(2 (n+1-max(i,j))))
+//                 / ((1-lam^2) (1-lam^(2(n+1)))),         lam = 2 - sqrt(3),
+// and lam^35 < 1e-20, so every moment is a 69-term local sum: no sequential sweep over the (possibly tens
+// of thousands of) knots of a run, and only the distance to the run's ends up to 40 knots is ever needed.
+#define SPL_W 34
+#define SPL_CAP 40
+#define SPL_BIG 1000000
 
-  int rs = -1;
-  for (int i = 0; i <= No_ti; ++i) {
-    const bool a = (i < No_ti) && ACC(i);
-    if (a) {
-      if (rs < 0) rs = i;
-      continue;
-    }
-    if (i < No_ti) {
-      mom[(size_t)i * ld + k] = 0.0;
-      if (k < Kmax) code[(size_t)i * Kmax + k] = 0;
-    }
-    if (rs < 0) continue;
-    const int m = i - rs;  // run rs .. i-1
-    if (m < 4) {
-      for (int q = 0; q < m; ++q) {
-        mom[(size_t)(rs + q) * ld + k] = 0.0;
-        if (k < Kmax) code[(size_t)(rs + q) * Kmax + k] = (m == 1) ? 1 : (unsigned char)(16 + 4 * m + q);
-      }
-    } else {
-      // not-a-knot, uniform spacing: 6*M_1 = d_1, 6*M_{m-2} = d_{m-2}; (1,4,1) system in between
-      const double M1 = D2(rs + 1) / 6.0;
-      const double Mm2 = D2(rs + m - 2) / 6.0;
-      if (m >= 5) {
-        double cprev = 0.0, dprev = 0.0;
-        for (int q = 2; q <= m - 3; ++q) {
-          double rhs = D2(rs + q);
-          if (q == 2) rhs -= M1;
-          if (q == m - 3) rhs -= Mm2;
-          double den = (q == 2) ? 4.0 : 4.0 - cprev;
-          double cq = 1.0 / den;
-          double dq = ((q == 2) ? rhs : rhs - dprev) / den;
-          cp[(size_t)(rs + q) * ld + k] = cq;
-          dp[(size_t)(rs + q) * ld + k] = dq;
-          cprev = cq; dprev = dq;
-        }
-        double Mnext = dprev;
-        mom[(size_t)(rs + m - 3) * ld + k] = Mnext;
-        for (int q = m - 4; q >= 2; --q) {
-          double Mq = dp[(size_t)(rs + q) * ld + k] - cp[(size_t)(rs + q) * ld + k] * Mnext;
-          mom[(size_t)(rs + q) * ld + k] = Mq;
-          Mnext = Mq;
-        }
-      }
-      mom[(size_t)(rs + 1) * ld + k] = M1;
-      mom[(size_t)(rs + m - 2) * ld + k] = Mm2;
-      const double M2 = mom[(size_t)(rs + 2) * ld + k];
-      const double Mm3 = mom[(size_t)(rs + m - 3) * ld + k];
-      mom[(size_t)rs * ld + k] = 2.0 * M1 - M2;
-      mom[(size_t)(rs + m - 1) * ld + k] = 2.0 * Mm2 - Mm3;
-      if (k < Kmax)
-        for (int q = 0; q < m; ++q) code[(size_t)(rs + q) * Kmax + k] = 2;
-    }
-    rs = -1;
+struct SplineCol {
+  const double* rec; int RS, off_y, off_acc, No_ti; bool all_acc; double h2;
+  __device__ double y(int i) const { return rec[(size_t)i * RS + off_y]; }
+  __device__ bool acc(int i) const {
+    return i >= 0 && i < No_ti && (all_acc || rec[(size_t)i * RS + off_acc] != 0.0);
   }
+  __device__ double d2(int i) const { return 6.0 * ((y(i - 1) - 2.0 * y(i)) + y(i + 1)) / h2; }
+};
+
+__device__ inline double lam_pow(const double* lp, int e) { return e > 79 ? 0.0 : lp[e]; }
+
+// moment of a knot that is neither the first nor the last of its run; A / B = distance (in knots) to the
+// first / last knot of the run (>= 1), SPL_BIG when farther than SPL_CAP
+__device__ double inner_moment(const SplineCol& C, const double* lp, int i, int A, int B) {
+  if (A == 1 || B == 1) return C.d2(i) / 6.0;
+  const int dlo = (A >= SPL_BIG) ? -SPL_W : max(-SPL_W, 2 - A);
+  const int dhi = (B >= SPL_BIG) ? SPL_W : min(SPL_W, B - 2);
+  const double lam2 = lp[2];
+  const double np1 = (A >= SPL_BIG || B >= SPL_BIG) ? 0.0 : lam_pow(lp, 2 * (A + B - 2));  // lam^(2(n+1))
+  const double den = (1.0 - lam2) * (1.0 - np1);
+  double ym = C.y(i + dlo - 1), y0 = C.y(i + dlo), yp;
+  double acc = 0.0;
+  for (int d = dlo; d <= dhi; ++d) {
+    yp = C.y(i + d + 1);
+    const double h2 = C.h2;
+    double rhs = 6.0 * ((ym - 2.0 * y0) + yp) / h2;
+    if (A < SPL_BIG && A + d == 2) rhs -= C.d2(i + d - 1) / 6.0;   // first inner row: - M_1
+    if (B < SPL_BIG && B - d == 2) rhs -= C.d2(i + d + 1) / 6.0;   // last inner row:  - M_{m-2}
+    const int ad = d < 0 ? -d : d;
+    // min(i', j') = A-1+min(d,0);  n+1-max(i', j') = B-1-max(d,0)
+    const double fa = (A >= SPL_BIG) ? 1.0 : 1.0 - lam_pow(lp, 2 * (A - 1 + (d < 0 ? d : 0)));
+    const double fb = (B >= SPL_BIG) ? 1.0 : 1.0 - lam_pow(lp, 2 * (B - 1 - (d > 0 ? d : 0)));
+    double w = lam_pow(lp, ad + 1) * fa * fb / den;
+    acc += (ad & 1) ? -w * rhs : w * rhs;
+    ym = y0; y0 = yp;
+  }
+  return acc;
+}
+
+extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const double* __restrict__ records, int No_ti,
+                                                                      int Kmax, int step,
+                                                                      unsigned char* __restrict__ code,
+                                                                      double* __restrict__ mom) {
+  __shared__ double lp[80];
+  if (threadIdx.x < 80) lp[threadIdx.x] = pow(2.0 - sqrt(3.0), (double)threadIdx.x);
+  __syncthreads();
+  const int ld = Kmax + 1;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)No_ti * ld) return;
+  const int i = (int)(idx / ld), k = (int)(idx - (long long)i * ld);
+  SplineCol C;
+  C.rec = records; C.RS = 3 * Kmax + 1; C.No_ti = No_ti; C.all_acc = (k == Kmax);
+  C.off_y = (k == Kmax) ? 3 * Kmax : Kmax + k;
+  C.off_acc = (k == Kmax) ? 0 : k;
+  C.h2 = (double)step * (double)step;
+  double M = 0.0;
+  unsigned char cd = 0;
+  if (C.acc(i)) {
+    int dl = 0, dr = 0;
+    while (dl < SPL_CAP && C.acc(i - dl - 1)) ++dl;
+    while (dr < SPL_CAP && C.acc(i + dr + 1)) ++dr;
+    const bool kl = dl < SPL_CAP, kr = dr < SPL_CAP;
+    const int m = dl + dr + 1;
+    if (kl && kr && m < 4) {
+      cd = (m == 1) ? 1 : (unsigned char)(16 + 4 * m + dl);
+    } else {
+      cd = 2;
+      const int A = kl ? dl : SPL_BIG, B = kr ? dr : SPL_BIG;
+      if (A == 0) {
+        M = 2.0 * inner_moment(C, lp, i + 1, 1, B - 1) - inner_moment(C, lp, i + 2, 2, B - 2);
+      } else if (B == 0) {
+        M = 2.0 * inner_moment(C, lp, i - 1, A - 1, 1) - inner_moment(C, lp, i - 2, A - 2, 2);
+      } else {
+        M = inner_moment(C, lp, i, A, B);
+      }
+    }
+  }
+  mom[(size_t)i * ld + k] = M;
+  if (k < Kmax) code[(size_t)i * Kmax + k] = cd;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,14 +338,14 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double
 using namespace eaqhm;
 
 extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti,
-                                  int32_t Kmax, int32_t step, uint8_t* code, double* mom, double* work) {
+                                  int32_t Kmax, int32_t step, uint8_t* code, double* mom) {
   if (!ctx) return EAQHM_EINVAL;
-  if (!records || !code || !mom || !work || Kmax <= 0 || step <= 0)
+  if (!records || !code || !mom || Kmax <= 0 || step <= 0)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: bad argument");
   if (No_ti < 4) return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: need at least 4 analysis instants (interp1d kind=3)");
-  const int threads = 64, blocks = (Kmax + 1 + threads - 1) / threads;
-  hipLaunchKernelGGL(eaqhm_spline_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, records, No_ti, Kmax, step,
-                     code, mom, work);
+  const long long cells = (long long)No_ti * (Kmax + 1);
+  hipLaunchKernelGGL(eaqhm_spline_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, records, No_ti,
+                     Kmax, step, code, mom);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

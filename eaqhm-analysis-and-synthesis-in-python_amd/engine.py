@@ -153,7 +153,6 @@ class DeviceAnalysis:
         self.s_hat = [torch.zeros(L, dtype=f64, device=dev) for _ in range(2)]
         self.code = torch.zeros(T, K, dtype=torch.uint8, device=dev)
         self.mom = torch.zeros(T, K + 1, dtype=f64, device=dev)
-        self.work = torch.zeros(2, T, K + 1, dtype=f64, device=dev)
         self.partials = torch.zeros(self.ctx.eval_partials_len(0, L, p.step), dtype=f64, device=dev)
         self.sums = torch.zeros(4, dtype=f64, device=dev)
         self.raw = None
@@ -201,7 +200,7 @@ class DeviceAnalysis:
         p, c, sh = self.plan, self.ctx, self.shard
         sh.all_gather_rows(self.records[0], p.No_ti)
         e0 = self._mark()
-        c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom, self.work)
+        c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom)
         if self.s_hi > self.s_lo:
             c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
                          self.t_lo, self.t_hi, self.s_lo, self.s_hi, self.target, self.std_det, self.am_cur,

@@ -24,7 +24,7 @@ SYMBOLS = (
     ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _I32, _I32, _I32, _F64, _F64, _P, _P, _P]),
     ("eaqhm_ls_explicit", C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _P, _F64, _P, _P]),
-    ("eaqhm_spline_solve", C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    ("eaqhm_spline_solve", C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     ("eaqhm_eval_synth", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F64, _I64, _I64, _I64, _I64, _I64, _P, _F64,
                                     _P, _P, _P, _P, _P, _P]),
     ("eaqhm_eval_partials_len", _I64, [_I64, _I64, _I32]),
@@ -133,9 +133,8 @@ class Context:
         self._ck(self.lib.eaqhm_ls_explicit(self.h, _ptr(s), N, _ptr(am), _ptr(fm), _ptr(f0range), Kc, _ptr(window),
                                             float(fs), _ptr(out_amp), _ptr(out_slope)))
 
-    def spline_solve(self, records, No_ti, Kmax, step, code, mom, work):
-        self._ck(self.lib.eaqhm_spline_solve(self.h, _ptr(records), No_ti, Kmax, step, _ptr(code),
-                                             _ptr(mom), _ptr(work)))
+    def spline_solve(self, records, No_ti, Kmax, step, code, mom):
+        self._ck(self.lib.eaqhm_spline_solve(self.h, _ptr(records), No_ti, Kmax, step, _ptr(code), _ptr(mom)))
 
     def eval_synth(self, records, code, mom, No_ti, Kmax, step, fs, L, t_lo, t_hi, s_lo, s_hi, target, std_det,
                    am_out, fm_out, ph_knot, s_hat, partials, sums_out):

@@ -104,10 +104,9 @@ int eaqhm_ls_explicit(eaqhm_ctx* ctx, const double* s, int32_t N, const double* 
  * and :346-371 (per harmonic: runs of consecutive accepted instants, cubic through the knots).
  *   code[i][k]  uint8: 0 not accepted, 1 isolated accepted instant, 2 member of a run of >= 4 knots,
  *               16 + 4*m + pos for runs of m = 2 or 3 knots (pos = position inside the run)
- *   mom[i][k]   double[No_ti][Kmax+1] second derivatives of the fm splines (column Kmax: the a0 spline)
- *   work        double[2][No_ti][Kmax+1] scratch                                                      */
+ *   mom[i][k]   double[No_ti][Kmax+1] second derivatives of the fm splines (column Kmax: the a0 spline) */
 int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti, int32_t Kmax, int32_t step,
-                       uint8_t* code, double* mom, double* work);
+                       uint8_t* code, double* mom);
 
 /* interpolation stage 2 + synthesis + SRER -----------------------------------------------------------
  * Replaces functions.py:364 (linear am), :367-371 (cubic fm, incl. the <4-knot padded case),

@@ -1,0 +1,159 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the host
+logic (prologue, frame plan, struct packing) matches the reference-generated fixtures, the product path
+fails loudly without a GPU, and the N>1 path (instant sharding + in-place all-gather + halo ranges) is
+exercised with world_size=2 over gloo using the oracle-backed stand-in backend of tests/fake_backend.py."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden
+
+
+def test_library_exports_every_header_symbol():
+    import eaqhm_amd  # noqa: F401
+    from eaqhm_amd.hip import SYMBOLS, load_library
+    lib = load_library()
+    header = open(os.path.join(ROOT, "include", "eaqhm_hip.h")).read()
+    declared = set(re.findall(r"\b(eaqhm_[a-z_0-9]+)\s*\(", header))
+    declared.discard("eaqhm_ctx")
+    bound = {n for n, _, _ in SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product raises; it never routes through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import eaqhm_amd
+    with pytest.raises(eaqhm_amd.HipUnavailable):
+        eaqhm_amd.iqhmLS_complexamps(np.zeros(5), np.ones(1), np.ones(5), 16000)
+    g = load_golden("sa19_female_default.npz")
+    with pytest.raises(eaqhm_amd.HipUnavailable):
+        eaqhm_amd.eaQHMAnalysisAndSynthesis(os.path.join(GOLDEN, "SA19.WAV"), "female", printPrompts=False,
+                                            pitch_track=g["swipe_track"])
+    pkg = os.path.join(ROOT, "eaqhm-analysis-and-synthesis-in-python_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("no CPU", ""), fn
+
+
+def test_prologue_and_plan_sa19(sa19_golden):
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import FramePlan
+    g = sa19_golden
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    assert fs == 16000 and len(s) == 63488
+    assert prologue.pitch_limits("female") == (160, 300) and prologue.pitch_limits((90, 400)) == (90, 400)
+    assert prologue.pitch_limits("x") == (70, 500) and prologue.pitch_limits("male") == (70, 180)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    assert fstep == int(g["frame_step"])
+    assert np.array_equal([f.isSpeech for f in frames], g["vuv_isSpeech"])
+    assert np.array_equal([f.isVoiced for f in frames], g["vuv_isVoiced"])
+    grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    assert np.abs(grid - g["f0s_5ms"]).max() == 0
+    u = load_golden("unit_vectors.npz")
+    assert np.abs(prologue.resample_track(u["gl_v"], u["gl_t"]) - u["gl_out"]).max() == 0
+    prologue.apply_full_waveform(frames, len(s), 480)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    assert (plan.Kmax, plan.No_ti, plan.n_frames) == (59, 4233, 4169)
+    assert np.array_equal(plan.ti[plan.analysed], g["ti_a0"]) and np.abs(plan.frame_f0 - g["f0_a0"]).max() == 0
+    assert np.array_equal(2 * plan.frame_wl + 1, g["ls_shapes_iqhm"][:, 0])
+    assert np.array_equal(2 * plan.frame_K + 1, g["ls_shapes_iqhm"][:, 1])
+    assert plan.f0_stale == g["stale_f0"][0, 1]
+
+
+def test_voiced_only_target_and_flags():
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import FramePlan
+    g = load_golden("sa19_female_voicedonly_adpt1.npz")
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    plan = FramePlan(len(s), fs, g["f0s_5ms"], frames, fstep, 15, 3, 32, 0)
+    assert np.array_equal(plan.in_bounds, g["det_isSpeech"]) and np.array_equal(plan.analysed, g["det_isVoiced"])
+    import eaqhm_oracle as O
+    ti5 = np.array([f.ti for f in frames])
+    ref = O.voiced_only_target(s, ti5, g["vuv_isSpeech"], g["vuv_isVoiced"], fstep)
+    assert np.array_equal(prologue.voiced_only_target(s, frames, fstep), ref)
+
+
+def test_struct_packing_quirks(sa19_golden):
+    from eaqhm_amd.functions import _slot_array
+    from eaqhm_amd.structs import Deterministic, Frame
+    d = Deterministic(ti=np.int64(5), isSpeech=True, isVoiced=True)
+    assert d.ak == [] and d.a0 == [] and d.frange == [] and d.pk == [] and not hasattr(d, "amplitudes")
+    assert "isVoiced" in str(d) and str(Frame(1, True, 0.5)).startswith("{")
+    arr = _slot_array(np.array([0, 2, 5]), np.array([1.5, 2.5, 3.5]))
+    q = load_golden("unit_vectors.npz")["abi_dtype"]
+    assert str(arr.dtype) == q[0] and str(arr.shape) == q[1] and type(arr[1]).__name__ == q[2]
+    assert str(np.shape(arr[0])) == q[3] and arr[2][0] == 2.5 and arr[1] == 0
+
+
+def test_sharding_ranges():
+    from eaqhm_amd.engine import Sharding
+    for world in (1, 2, 3, 8):
+        for T in (7, 16, 4233):
+            got = [Sharding(r, world).instants(T) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == T
+            assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+            assert max(h - l for l, h in got) <= -(-T // world)
+
+
+# ----------------------------------------------------------------------------- world_size = 2 over gloo
+def _sharded_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_backend import OracleBackend
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan, Sharding
+    from eaqhm_amd.synth import synth_speech_int16
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(limits=2)          # two ranks share the CI container's 8 cores
+    fs = 16000
+    s = synth_speech_int16(0.62, fs) / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    grid = prologue.resample_track(np.column_stack([t, f0]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 480)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    eng = DeviceAnalysis(s, s, plan, 160, 2, shard=Sharding(rank, world, dist.group.WORLD), ctx=OracleBackend())
+    eng.run()
+    fin = eng.final_arrays()
+    if rank == 0:
+        np.savez(out_path, SRER=np.array(eng.SRER), n_frames_rank0=eng.n_ls_frames, **fin)
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.synth import synth_speech_int16
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_sharded_worker, args=(2, 29000 + os.getpid() % 2000, out), nprocs=2, join=True)
+    got = np.load(out)
+    fs = 16000
+    s = synth_speech_int16(0.62, fs) / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    grid = prologue.resample_track(np.column_stack([t, f0]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    ref = O.analyse(s, fs, grid, np.array([f.ti for f in frames]), np.array([float(f.isSpeech) for f in frames]),
+                    np.array([float(f.isVoiced) for f in frames]), fstep, f0min=160, maxAdpt=2)
+    assert len(got["SRER"]) == len(ref["SRER"])
+    assert np.abs(got["SRER"] - np.array(ref["SRER"])).max() < 1e-9
+    assert np.abs(got["s_recon"] - ref["s_recon"]).max() < 1e-11
+    assert np.abs(got["am"] - ref["am"]).max() < 1e-12 and np.abs(got["fm"] - ref["fm"]).max() < 1e-7
+    assert np.abs(got["pk"] - ref["pk"]).max() < 1e-9 and np.abs(got["a0"] - ref["a0"]).max() < 1e-12
+    assert 0 < int(got["n_frames_rank0"]) < ref["n_ls_frames"]      # rank 0 analysed only its share

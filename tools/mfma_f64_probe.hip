@@ -18,7 +18,8 @@ __global__ void layout_kernel(const double* A, const double* B, double* D) {
 }
 
 template <int NACC>
-__global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double x) {
+__global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double x, unsigned long long* clk = nullptr) {
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   d4 acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
   double a = x + threadIdx.x * 1e-3, b = x - threadIdx.x * 1e-3;
@@ -29,6 +30,10 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, doubl
   double s = 0;
   for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (clk && threadIdx.x == 0 && blockIdx.x == 0) {
+    clk[0] = __builtin_amdgcn_s_memtime() - t0;
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
 }
 
 __global__ void __launch_bounds__(256) fma_kernel(double* out, int iters, double x) {
@@ -115,6 +120,23 @@ int main() {
     printf("MFMA f64 2 acc (dependent chains), 1 wave/SIMD: %.1f cyc/mfma\n", ms * 1e-3 * 2.4e9 / (iters * 2.0));
     ms = time_ms([&] { rate_kernel<1><<<ncu, 256>>>(out, iters, 1.0); }, 5);
     printf("MFMA f64 1 acc (dependent chain), 1 wave/SIMD: %.1f cyc/mfma\n", ms * 1e-3 * 2.4e9 / (iters * 1.0));
+  }
+  {
+    unsigned long long* clk; CK(hipMalloc(&clk, 16));
+    int longit = 200000;
+    for (int bpc = 1; bpc <= 8; bpc *= 2) {
+      int blocks = ncu * bpc;
+      float ms;
+      if (bpc <= 2) ms = time_ms([&] { rate_kernel<8><<<blocks, 256>>>(out, longit, 1.0, clk); }, 2);
+      else if (bpc == 4) ms = time_ms([&] { rate_kernel<4><<<blocks, 256>>>(out, longit, 1.0, clk); }, 2);
+      else ms = time_ms([&] { rate_kernel<2><<<blocks, 256>>>(out, longit, 1.0, clk); }, 2);
+      int nacc = bpc <= 2 ? 8 : (bpc == 4 ? 4 : 2);
+      unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+      double ghz = (double)h[0] / (double)h[1] * 0.1;
+      double flops = (double)blocks * 4 * longit * nacc * 2048.0;
+      printf("LONG MFMA f64: %d waves/SIMD, %d acc: %.1f ms %.1f TFLOP/s, in-kernel clock %.2f GHz, %.1f shader-cyc per mfma per SIMD\n", bpc, nacc, ms,
+             flops / ms / 1e9, ghz, ms * 1e-3 * ghz * 1e9 / ((double)bpc * longit * nacc));
+    }
   }
   for (int bpc = 1; bpc <= 4; bpc *= 2) {
     int blocks = ncu * bpc;
