@@ -50,3 +50,12 @@ extern "C" int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]) {
   h_info[3] = EAQHM_ABI_VERSION;
   return EAQHM_OK;
 }
+
+extern "C" int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (key == EAQHM_OPT_LS_VARIANT && (value >= 1 && value <= 3)) {
+    ctx->ls_variant = value;
+    return EAQHM_OK;
+  }
+  return ctx->fail(EAQHM_EINVAL, "eaqhm_set_option: unknown key or value");
+}

@@ -13,9 +13,14 @@
 //
 // Column order of the LS unknowns: [n negative columns | DC | n positive columns], Kc = 2n+1, then the
 // same again for the slopes (functions.py:455 / :519: E = [E2, n*E2]).
-#include "eaqhm_common.h"
+#include "eaqhm_ls_common.h"
 
 namespace eaqhm {
+int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb);  // eaqhm_ls_mfma.hip
+size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax);
+int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid);              // eaqhm_ls_tile.hip
+size_t ls_tile_scratch_stride(int nmax, int Nmax);
+
 
 // ------------------------------------------------------------------------------------------------
 // scratch carve-up (doubles) for one workgroup
@@ -87,102 +92,6 @@ __device__ void gram_to_system(const double* __restrict__ Xre, const double* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Phase C: left-looking Cholesky on the transposed storage (coalesced over rows), RHS as row M, then
-// back substitution by wave 0.  Result x (M complex) in LDS `xs` (interleaved).
-__device__ void cholesky_solve(double* __restrict__ Lt, int M, int ldl, double* rowj, double* xs, double* sh) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = 0; j < M; ++j) {
-    // row j of L (entries k < j) -> LDS
-    for (int k = tid; k < j; k += nt) {
-      size_t o = ((size_t)k * ldl + j) * 2;
-      rowj[2 * k] = Lt[o];
-      rowj[2 * k + 1] = Lt[o + 1];
-    }
-    __syncthreads();
-    for (int i = j + tid; i <= M; i += nt) {
-      size_t oj = ((size_t)j * ldl + i) * 2;
-      double ar = Lt[oj], ai = Lt[oj + 1];
-      for (int k = 0; k < j; ++k) {
-        size_t o = ((size_t)k * ldl + i) * 2;
-        double lr = Lt[o], li = Lt[o + 1];
-        double cr = rowj[2 * k], ci = rowj[2 * k + 1];
-        ar -= lr * cr + li * ci;  // L[i][k] * conj(L[j][k])
-        ai -= li * cr - lr * ci;
-      }
-      if (i == j) {
-        double d = sqrt(ar);
-        sh[0] = d;
-        Lt[oj] = d; Lt[oj + 1] = 0.0;
-      } else {
-        Lt[oj] = ar; Lt[oj + 1] = ai;  // scaled below
-      }
-    }
-    __syncthreads();
-    double inv = 1.0 / sh[0];
-    for (int i = j + 1 + tid; i <= M; i += nt) {
-      size_t oj = ((size_t)j * ldl + i) * 2;
-      Lt[oj] *= inv; Lt[oj + 1] *= inv;
-    }
-    __syncthreads();
-  }
-  // back substitution: y_j = conj(L[M][j]); x_j = (y_j - sum_{i>j} conj(L[i][j]) x_i) / L[j][j]
-  if (tid < 64) {
-    for (int j = M - 1; j >= 0; --j) {
-      const double* row = Lt + (size_t)j * ldl * 2;
-      double sr = 0, si = 0;
-      for (int i = j + 1 + tid; i < M; i += 64) {
-        double lr = row[2 * i], li = row[2 * i + 1];
-        double xr = xs[2 * i], xi = xs[2 * i + 1];
-        sr += lr * xr + li * xi;  // conj(l) * x
-        si += lr * xi - li * xr;
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        sr += __shfl_xor(sr, o);
-        si += __shfl_xor(si, o);
-      }
-      if (tid == 0) {
-        double d = row[2 * j];
-        double yr = row[2 * M], yi = -row[2 * M + 1];
-        xs[2 * j] = (yr - sr) / d;
-        xs[2 * j + 1] = (yi - si) / d;
-      }
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-    }
-  }
-  __syncthreads();
-}
-
-// numpy.blackman / numpy.hamming (symmetric form: n = 2u - (N-1))
-__device__ inline double window_value(int mode_blackman, int u, int N) {
-  double n = (double)(2 * u - (N - 1));
-  double den = (double)(N - 1);
-  if (mode_blackman) return 0.42 + 0.5 * cos(M_PI * n / den) + 0.08 * cos(2.0 * M_PI * n / den);
-  return 0.54 + 0.46 * cos(M_PI * n / den);
-}
-
-struct LsArgs {
-  int mode;  // 0: adaptation 0 (stationary harmonics), 1: adaptation >= 1 (tracks)
-  const double* s; long long L; double fs;
-  const double* am_cur; const double* fm_cur; int Kmax;
-  const int* frame_inst; const int* frame_c; const int* frame_wl; const double* frame_f0; const int* frame_K;
-  const int* ncol; const int* cols; const unsigned char* seeded; const int* any_seed;
-  int n_frames; int a_iter; double f0_stale; double f0min;
-  double* records; double* raw_amp; double* raw_slope;
-  double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
-};
-
-// seed-aware track access (functions.py:209-210; see eaqhm_frame_prep)
-__device__ inline double track_fm(const LsArgs& A, int k, long long t, int c, bool seeds) {
-  if (seeds && k == 0 && t <= c && A.seeded[t]) return 140.0;
-  return A.fm_cur[(size_t)k * A.L + t];
-}
-__device__ inline double track_am(const LsArgs& A, int k, long long t, int c, bool seeds) {
-  if (seeds && k == 0 && t <= c && A.seeded[t]) return 10e-4;
-  return A.am_cur[(size_t)k * A.L + t];
-}
-
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -194,7 +103,6 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
   double* rho = xs + 2 * Mmax;      // 2*nmax
   double* sh = rho + 2 * A.nmax;    // 8
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
-  const double eps = 10e-5;  // functions.py:517
 
   for (int f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
@@ -215,61 +123,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
       S.Xim[(size_t)u * ldx + Kc] = 0.0;
     }
     if (A.mode == 1) {
-      // A1: one thread per active slot: gap fill, running sums from the middle outwards, ratios
-      for (int j = tid; j < n; j += nt) {
-        const int k = mycols[j];
-        const long long t0 = (long long)c - wl;
-        double* Qc = S.Q + j;  // element u+1 at Qc[(u+1)*n]
-        double* rc = S.r + j;  // element u   at rc[u*n]
-        int last = -1;
-        double ylo_f = 0, ylo_a = 0;
-        for (int u = 0; u < N; ++u) {
-          double v = track_fm(A, k, t0 + u, c, seeds);
-          if (v != 0.0) {
-            double va = track_am(A, k, t0 + u, c, seeds);
-            if (last < u - 1) {
-              if (last < 0) {  // leading gap: hold (functions.py:259-263)
-                for (int g = 0; g < u; ++g) { Qc[(size_t)(g + 1) * n] = v; rc[(size_t)g * n] = va; }
-              } else {         // interior gap: linear (functions.py:277-278)
-                double dx = (double)(u - last);
-                double sf = (v - ylo_f) / dx, sa = (va - ylo_a) / dx;
-                for (int g = last + 1; g < u; ++g) {
-                  double xx = (double)(g - last);
-                  Qc[(size_t)(g + 1) * n] = sf * xx + ylo_f;
-                  rc[(size_t)g * n] = sa * xx + ylo_a;
-                }
-              }
-            }
-            Qc[(size_t)(u + 1) * n] = v;
-            rc[(size_t)u * n] = va;
-            last = u; ylo_f = v; ylo_a = va;
-          }
-        }
-        for (int g = last + 1; g < N; ++g) {  // trailing gap: hold (functions.py:265-271)
-          Qc[(size_t)(g + 1) * n] = ylo_f; rc[(size_t)g * n] = ylo_a;
-        }
-        // running sums relative to the middle: Q[u] = sum_{v<=u} fm[v] - sum_{v<=mid} fm[v]
-        const double fmid = Qc[(size_t)(mid + 1) * n];
-        double acc = 0.0;
-        Qc[(size_t)(mid + 1) * n] = 0.0;
-        for (int u = mid + 1; u < N; ++u) {
-          acc += Qc[(size_t)(u + 1) * n];
-          Qc[(size_t)(u + 1) * n] = acc;
-        }
-        acc = 0.0;
-        double fnext = fmid;
-        for (int u = mid - 1; u >= -1; --u) {
-          double tmp = (u >= 0) ? Qc[(size_t)(u + 1) * n] : 0.0;
-          acc -= fnext;
-          Qc[(size_t)(u + 1) * n] = acc;
-          fnext = tmp;
-        }
-        const double amid = rc[(size_t)mid * n] + eps;
-        for (int u = 0; u < N; ++u) rc[(size_t)u * n] = (eps + rc[(size_t)u * n]) / amid;
-        double sn, cs;
-        sincos((2.0 * M_PI * fmid) / A.fs, &sn, &cs);
-        rho[2 * j] = cs; rho[2 * j + 1] = sn;
-      }
+      fill_columns(A, S.Q, S.r, rho, mycols, n, N, mid, c, wl, seeds);
       __syncthreads();
       // A3: one sincos per (sample, positive column); it feeds the positive column at u and the
       // negative column at N-2-u (time-reversed, functions.py:284-285)
@@ -315,49 +169,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
     cholesky_solve(S.Lt, M, ldl, rowj, xs, sh);
 
     // ---------------- Phase D ----------------
-    if (A.raw_amp) {
-      const int stride = 2 * (2 * A.Kmax + 1);
-      for (int q = tid; q < 2 * Kc; q += nt) {
-        A.raw_amp[(size_t)f * stride + q] = xs[q];
-        A.raw_slope[(size_t)f * stride + q] = xs[2 * Kc + q];
-      }
-    }
-    // amplitude floor over the positive slots (functions.py:309)
-    double amax = 0.0;
-    for (int j = tid; j < n; j += nt) {
-      double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
-      amax = fmax(amax, hypot(ar, ai));
-    }
-    for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
-    if ((tid & 63) == 0) sh[1 + (tid >> 6)] = amax;
-    __syncthreads();
-    amax = fmax(fmax(sh[1], sh[2]), fmax(sh[3], sh[4]));
-    const double floor_db = 20.0 * log10(amax) - 150.0;
-    const double h = f0 / (double)(A.a_iter + 1);  // functions.py:310
-    double* rec = A.records + (size_t)inst * (3 * A.Kmax + 1);
-    for (int k = tid; k < 3 * A.Kmax; k += nt) rec[k] = 0.0;
-    __syncthreads();
-    for (int j = tid; j < n; j += nt) {
-      const int k = (A.mode == 0) ? j : mycols[j];
-      double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
-      double br = xs[2 * (Kc + n + 1 + j)], bi = xs[2 * (Kc + n + 1 + j) + 1];
-      double mag = hypot(ar, ai);
-      double eta = 0.0;
-      if (A.mode == 1) eta = A.fs / (2.0 * M_PI) * ((ar * bi - ai * br) / (mag * mag));  // functions.py:297
-      if (20.0 * log10(mag) > floor_db && fabs(eta) < h) {
-        rec[k] = mag;
-        rec[2 * A.Kmax + k] = atan2(ai, ar);
-        double fmv;
-        if (A.mode == 0) fmv = (double)(k + 1) * f0;
-        else {
-          double cur = track_fm(A, k, c, c, seeds);
-          fmv = (f0 > A.f0min) ? cur + eta : cur;
-        }
-        rec[A.Kmax + k] = fmv;
-      }
-    }
-    if (tid == 0) rec[3 * A.Kmax] = xs[2 * n];  // Re(a_DC) (functions.py:303)
-    __syncthreads();
+    write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
   }
 }
 
@@ -485,6 +297,31 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   if (n_frames == 0) return EAQHM_OK;
   if (wl_max <= 0) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: wl_max must be positive");
   const int nmax = Kmax, Nmax = 2 * wl_max + 1, Kcmax = 2 * Kmax + 1;
+  if (ctx->ls_variant >= 2) {
+    LsArgs B;
+    B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.am_cur = am_cur; B.fm_cur = fm_cur; B.Kmax = Kmax;
+    B.frame_inst = frame_inst; B.frame_c = frame_c; B.frame_wl = frame_wl; B.frame_f0 = frame_f0; B.frame_K = frame_K;
+    B.ncol = ncol; B.cols = cols; B.seeded = seeded; B.any_seed = any_seed; B.n_frames = n_frames; B.a_iter = a_iter;
+    B.f0_stale = f0_stale; B.f0min = f0min; B.records = records; B.raw_amp = raw_amp; B.raw_slope = raw_slope;
+    B.nmax = nmax; B.Nmax = Nmax; B.Kcmax = Kcmax;
+    int grid = ctx->n_cu < n_frames ? ctx->n_cu : n_frames;
+    const size_t st_m = ls_mfma_scratch_stride(nmax, Nmax, Kcmax), st_t = ls_tile_scratch_stride(nmax, Nmax);
+    int rc = ctx->reserve((st_m > st_t ? st_m : st_t) * grid * sizeof(double) + 256);
+    if (rc) return rc;
+    int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 2 * sizeof(int), ctx->stream));
+    B.scratch = (double*)ctx->scratch;
+    int min_nb = 0;
+    if (ctx->ls_variant == 3) {   // small frames: everything in registers/LDS; the rest falls through
+      B.scratch_stride = st_t; B.work_counter = counters;
+      rc = launch_ls_tile(ctx, B, grid);
+      if (rc) return rc;
+      min_nb = 7;
+      if (Kcmax + 1 <= 16 * 6) return EAQHM_OK;   // no frame can be larger: skip the second launch
+    }
+    B.scratch_stride = st_m; B.work_counter = counters + 1;
+    return launch_ls_mfma(ctx, B, grid, min_nb);
+  }
   const size_t stride = (ls_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
   int grid = ctx->n_cu * 2;
   if (grid > n_frames) grid = n_frames;
@@ -496,7 +333,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
   A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
   A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
-  A.Kcmax = Kcmax;
+  A.Kcmax = Kcmax; A.work_counter = nullptr;
   size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -1,0 +1,255 @@
+// eaqhm_ls_common.h — device pieces shared by the LS kernels (gfx950 only, FP64).
+//
+// Column order of the LS unknowns everywhere: [n negative columns | DC | n positive columns], Kc = 2n+1,
+// then the same again for the slopes (functions.py:455 / :519: E = [E2, n*E2]).
+#pragma once
+#include "eaqhm_common.h"
+
+namespace eaqhm {
+
+struct LsArgs {
+  int mode;  // 0: adaptation 0 (stationary harmonics), 1: adaptation >= 1 (tracks)
+  const double* s; long long L; double fs;
+  const double* am_cur; const double* fm_cur; int Kmax;
+  const int* frame_inst; const int* frame_c; const int* frame_wl; const double* frame_f0; const int* frame_K;
+  const int* ncol; const int* cols; const unsigned char* seeded; const int* any_seed;
+  int n_frames; int a_iter; double f0_stale; double f0min;
+  double* records; double* raw_amp; double* raw_slope;
+  double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
+  int* work_counter;  // dynamic frame queue (v2); may be null
+};
+
+// seed-aware track access (functions.py:209-210; see eaqhm_frame_prep): a seeded row shows 140 Hz / 10e-4
+// in slot 0 to the frames at or after it, exactly like the sequential write of the reference
+__device__ inline double track_fm(const LsArgs& A, int k, long long t, int c, bool seeds) {
+  if (seeds && k == 0 && t <= c && A.seeded[t]) return 140.0;
+  return A.fm_cur[(size_t)k * A.L + t];
+}
+__device__ inline double track_am(const LsArgs& A, int k, long long t, int c, bool seeds) {
+  if (seeds && k == 0 && t <= c && A.seeded[t]) return 10e-4;
+  return A.am_cur[(size_t)k * A.L + t];
+}
+
+// sin and cos of a double in one go with a small register footprint: 3-term Cody-Waite reduction by pi/2
+// through FMAs (exact products), then the fdlibm kernel polynomials on [-pi/4, pi/4].  Error < 1 ulp for
+// |x| < ~1e8 (basis phases here are below 1e4 rad).  The libm sincos() spills the MFMA accumulators that are
+// live across the basis build; this one does not.
+__device__ inline void sincos_cw(double x, double* sn, double* cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = fma(-n, 1.57079632679489655800e+00, x);       // pi/2 split in three doubles
+  r = fma(-n, 6.12323399573676603587e-17, r);
+  r = fma(-n, -1.49738490485916983294e-33, r);
+  const double z = r * r;
+  // fdlibm __kernel_sin / __kernel_cos coefficients
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double s0 = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double c0 = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)n & 3;
+  const double sv = (q & 1) ? c0 : s0, cv = (q & 1) ? s0 : c0;
+  *sn = (q & 2) ? -sv : sv;
+  *cs = ((q + 1) & 2) ? -cv : cv;
+}
+
+// numpy.blackman / numpy.hamming (symmetric form: n = 2u - (N-1))
+__device__ inline double window_value(int blackman, int u, int N) {
+  double n = (double)(2 * u - (N - 1));
+  double den = (double)(N - 1);
+  double s1, c1;
+  sincos_cw(M_PI * n / den, &s1, &c1);
+  if (!blackman) return 0.54 + 0.46 * c1;
+  double s2, c2;
+  sincos_cw(2.0 * M_PI * n / den, &s2, &c2);
+  return 0.42 + 0.5 * c1 + 0.08 * c2;
+}
+
+// Phase A1 (adaptation >= 1): one thread per active slot windows its track, bridges zero gaps
+// (functions.py:251-278: interior gaps linearly, edge gaps held; positions decided on fm, applied to fm and
+// am), forms the running sums of fm relative to the window middle and the amplitude ratios
+// (functions.py:508-518), and leaves exp(j*2*pi*fm[mid]/fs) in rho.
+// Q is (N+1) x n: row u+1 <-> sample u, row 0 = the virtual sample u = -1;  r is N x n.
+__device__ inline void fill_columns(const LsArgs& A, double* Q, double* r, double* rho, const int* mycols, int n, int N,
+                                    int mid, int c, int wl, bool seeds) {
+  const double eps = 10e-5;  // functions.py:517
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int k = mycols[j];
+    const long long t0 = (long long)c - wl;
+    double* Qc = Q + j;  // sample u at Qc[(u+1)*n]
+    double* rc = r + j;  // sample u at rc[u*n]
+    int last = -1;
+    double ylo_f = 0, ylo_a = 0;
+    for (int u = 0; u < N; ++u) {
+      double v = track_fm(A, k, t0 + u, c, seeds);
+      if (v != 0.0) {
+        double va = track_am(A, k, t0 + u, c, seeds);
+        if (last < u - 1) {
+          if (last < 0) {  // leading gap: hold (functions.py:259-263)
+            for (int g = 0; g < u; ++g) { Qc[(size_t)(g + 1) * n] = v; rc[(size_t)g * n] = va; }
+          } else {         // interior gap: linear (functions.py:277-278)
+            double dx = (double)(u - last);
+            double sf = (v - ylo_f) / dx, sa = (va - ylo_a) / dx;
+            for (int g = last + 1; g < u; ++g) {
+              double xx = (double)(g - last);
+              Qc[(size_t)(g + 1) * n] = sf * xx + ylo_f;
+              rc[(size_t)g * n] = sa * xx + ylo_a;
+            }
+          }
+        }
+        Qc[(size_t)(u + 1) * n] = v;
+        rc[(size_t)u * n] = va;
+        last = u; ylo_f = v; ylo_a = va;
+      }
+    }
+    for (int g = last + 1; g < N; ++g) {  // trailing gap: hold (functions.py:265-271)
+      Qc[(size_t)(g + 1) * n] = ylo_f; rc[(size_t)g * n] = ylo_a;
+    }
+    // running sums relative to the middle: Q[u] = sum_{v<=u} fm[v] - sum_{v<=mid} fm[v]
+    const double fmid = Qc[(size_t)(mid + 1) * n];
+    double acc = 0.0;
+    Qc[(size_t)(mid + 1) * n] = 0.0;
+    for (int u = mid + 1; u < N; ++u) {
+      acc += Qc[(size_t)(u + 1) * n];
+      Qc[(size_t)(u + 1) * n] = acc;
+    }
+    acc = 0.0;
+    double fnext = fmid;
+    for (int u = mid - 1; u >= -1; --u) {
+      double tmp = (u >= 0) ? Qc[(size_t)(u + 1) * n] : 0.0;
+      acc -= fnext;
+      Qc[(size_t)(u + 1) * n] = acc;
+      fnext = tmp;
+    }
+    const double amid = rc[(size_t)mid * n] + eps;
+    for (int u = 0; u < N; ++u) rc[(size_t)u * n] = (eps + rc[(size_t)u * n]) / amid;
+    double sn, cs;
+    sincos_cw((2.0 * M_PI * fmid) / A.fs, &sn, &cs);
+    rho[2 * j] = cs; rho[2 * j + 1] = sn;
+  }
+}
+
+// Phase C (round-1 form): left-looking complex Cholesky on transposed storage Lt[k][i] = R[i][k] (coalesced
+// over rows), the right-hand side carried as row M (so the forward solve comes for free), then back
+// substitution by wave 0.  Result x (M complex, interleaved) in LDS `xs`.
+__device__ inline void cholesky_solve(double* __restrict__ Lt, int M, int ldl, double* rowj, double* xs, double* sh) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = 0; j < M; ++j) {
+    for (int k = tid; k < j; k += nt) {  // row j of L (entries k < j) -> LDS
+      size_t o = ((size_t)k * ldl + j) * 2;
+      rowj[2 * k] = Lt[o];
+      rowj[2 * k + 1] = Lt[o + 1];
+    }
+    __syncthreads();
+    for (int i = j + tid; i <= M; i += nt) {
+      size_t oj = ((size_t)j * ldl + i) * 2;
+      double ar = Lt[oj], ai = Lt[oj + 1];
+      for (int k = 0; k < j; ++k) {
+        size_t o = ((size_t)k * ldl + i) * 2;
+        double lr = Lt[o], li = Lt[o + 1];
+        double cr = rowj[2 * k], ci = rowj[2 * k + 1];
+        ar -= lr * cr + li * ci;  // L[i][k] * conj(L[j][k])
+        ai -= li * cr - lr * ci;
+      }
+      if (i == j) {
+        double d = sqrt(ar);
+        sh[0] = d;
+        Lt[oj] = d; Lt[oj + 1] = 0.0;
+      } else {
+        Lt[oj] = ar; Lt[oj + 1] = ai;  // scaled below
+      }
+    }
+    __syncthreads();
+    double inv = 1.0 / sh[0];
+    for (int i = j + 1 + tid; i <= M; i += nt) {
+      size_t oj = ((size_t)j * ldl + i) * 2;
+      Lt[oj] *= inv; Lt[oj + 1] *= inv;
+    }
+    __syncthreads();
+  }
+  // back substitution: y_j = conj(L[M][j]); x_j = (y_j - sum_{i>j} conj(L[i][j]) x_i) / L[j][j]
+  if (tid < 64) {
+    for (int j = M - 1; j >= 0; --j) {
+      const double* row = Lt + (size_t)j * ldl * 2;
+      double sr = 0, si = 0;
+      for (int i = j + 1 + tid; i < M; i += 64) {
+        double lr = row[2 * i], li = row[2 * i + 1];
+        double xr = xs[2 * i], xi = xs[2 * i + 1];
+        sr += lr * xr + li * xi;  // conj(l) * x
+        si += lr * xi - li * xr;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o);
+        si += __shfl_xor(si, o);
+      }
+      if (tid == 0) {
+        double d = row[2 * j];
+        double yr = row[2 * M], yi = -row[2 * M + 1];
+        xs[2 * j] = (yr - sr) / d;
+        xs[2 * j + 1] = (yi - si) / d;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+  __syncthreads();
+}
+
+// Phase D: raw solution (optional), frequency mismatch (functions.py:297), amplitude floor and acceptance
+// (:309-315), record row (:316-324, :303).  xs = [amplitudes (Kc) | slopes (Kc)] interleaved complex in LDS;
+// sh needs 8 doubles (one partial maximum per wave at sh[1..]).
+__device__ inline void write_record(const LsArgs& A, const double* xs, double* sh, const int* mycols, int f, int n,
+                                    int inst, int c, double f0, bool seeds) {
+  const int tid = threadIdx.x, nt = blockDim.x, Kc = 2 * n + 1;
+  if (A.raw_amp) {
+    const int stride = 2 * (2 * A.Kmax + 1);
+    for (int q = tid; q < 2 * Kc; q += nt) {
+      A.raw_amp[(size_t)f * stride + q] = xs[q];
+      A.raw_slope[(size_t)f * stride + q] = xs[2 * Kc + q];
+    }
+  }
+  double amax = 0.0;  // amplitude floor over the positive slots (functions.py:309)
+  for (int j = tid; j < n; j += nt) {
+    double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
+    amax = fmax(amax, hypot(ar, ai));
+  }
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+  if ((tid & 63) == 0) sh[1 + (tid >> 6)] = amax;
+  __syncthreads();
+  amax = 0.0;
+  for (int w = 0; w < (nt >> 6); ++w) amax = fmax(amax, sh[1 + w]);
+  const double floor_db = 20.0 * log10(amax) - 150.0;
+  const double h = f0 / (double)(A.a_iter + 1);  // functions.py:310
+  double* rec = A.records + (size_t)inst * (3 * A.Kmax + 1);
+  for (int k = tid; k < 3 * A.Kmax; k += nt) rec[k] = 0.0;
+  __syncthreads();
+  for (int j = tid; j < n; j += nt) {
+    const int k = (A.mode == 0) ? j : mycols[j];
+    double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
+    double br = xs[2 * (Kc + n + 1 + j)], bi = xs[2 * (Kc + n + 1 + j) + 1];
+    double mag = hypot(ar, ai);
+    double eta = 0.0;
+    if (A.mode == 1) eta = A.fs / (2.0 * M_PI) * ((ar * bi - ai * br) / (mag * mag));  // functions.py:297
+    if (20.0 * log10(mag) > floor_db && fabs(eta) < h) {
+      rec[k] = mag;
+      rec[2 * A.Kmax + k] = atan2(ai, ar);
+      double fmv;
+      if (A.mode == 0) fmv = (double)(k + 1) * f0;
+      else {
+        double cur = track_fm(A, k, c, c, seeds);
+        fmv = (f0 > A.f0min) ? cur + eta : cur;
+      }
+      rec[A.Kmax + k] = fmv;
+    }
+  }
+  if (tid == 0) rec[3 * A.Kmax] = xs[2 * n];  // Re(a_DC) (functions.py:303)
+  __syncthreads();
+}
+
+}  // namespace eaqhm

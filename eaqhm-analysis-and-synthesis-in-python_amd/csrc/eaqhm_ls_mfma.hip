@@ -1,0 +1,253 @@
+// eaqhm_ls_mfma.hip — the per-frame LS with the Gramian on the FP64 matrix cores (gfx950).
+//
+// One workgroup of 512 threads (8 waves, 2 per SIMD) owns one frame at a time; frames are pulled from an
+// atomic queue (frames differ in size, so static striding leaves tails).
+//
+//   A1   one thread per active slot: track window, gap fill, running sums, amplitude ratios  -> global
+//        scratch Q, r ([sample][slot], slot fastest: coalesced for the next step)        (eaqhm_ls_common.h)
+//   A3+B time is cut into chunks of 16 sample PAIRS (u, N-2-u): the pair shares its sincos work because the
+//        negative-frequency column at u is the time-reversed positive one (functions.py:284-285).  All
+//        threads build the 32 basis rows of a chunk in LDS (planar re/im, [row][column], row stride
+//        ≡ 16 (mod 32) doubles so that the four 16-lane groups of an MFMA operand read hit disjoint
+//        banks); then every wave runs v_mfma_f64_16x16x4_f64 on its share of the (tile, weight) units:
+//            G_p[I][J] += X_I^H diag(w^2 n^p) X_J,  p = 0,1,2,
+//        4 real MFMAs per k-step (re·re + im·im, re·im - im·re), accumulators stay in registers for the
+//        whole frame.  The signal window is one more basis column, so the right-hand sides are tiles of
+//        the same contraction.
+//   C    system matrix [[G0,G1],[G1,G2]] + RHS row -> scratch, Cholesky + back substitution
+//   D    frequency mismatch, acceptance, record row                                     (eaqhm_ls_common.h)
+#include "eaqhm_ls_common.h"
+
+namespace eaqhm {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MF_THREADS 512
+#define MF_WAVES 8
+#define MF_NSLOT 8   // (tile, weight) units per wave per pass: 64 units = 21 complex tiles -> nb <= 6 in one pass
+
+struct MfScratch {
+  double* Q;   // (Nmax+1) * nmax
+  double* r;   // (Nmax+1) * nmax
+  double* Lt;  // Mmax * (Mmax+1) * 2
+};
+
+__host__ __device__ inline size_t mf_scratch_doubles(int nmax, int Nmax, int Kcmax) {
+  size_t M = 2 * (size_t)Kcmax;
+  return 2 * (size_t)(Nmax + 1) * nmax + 2 * M * (M + 1);
+}
+
+__device__ inline void tile_of(int q, int& I, int& J) {
+  I = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+  while ((I + 1) * (I + 2) / 2 <= q) ++I;
+  while (I * (I + 1) / 2 > q) --I;
+  J = q - I * (I + 1) / 2;
+}
+
+extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int TS, int ldx_max, int min_nb) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, nt = MF_THREADS;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the unit bookkeeping in SGPRs
+  const int Mmax = 2 * A.Kcmax;
+  double* Xre = lds;                         // TS * ldx_max
+  double* Xim = Xre + (size_t)TS * ldx_max;  // TS * ldx_max
+  double* Wp = Xim + (size_t)TS * ldx_max;   // 3 * TS   weights w^2 n^p per chunk row
+  double* rho = Wp + 3 * TS;                 // 2 * nmax
+  double* rowj = rho + 2 * A.nmax;           // 2 * Mmax
+  double* xs = rowj + 2 * Mmax;              // 2 * Mmax
+  double* sh = xs + 2 * Mmax;                // 16
+  int* shi = (int*)(sh + 12);
+  MfScratch S;
+  {
+    double* base = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    S.Q = base;
+    S.r = S.Q + (size_t)(A.Nmax + 1) * A.nmax;
+    S.Lt = S.r + (size_t)(A.Nmax + 1) * A.nmax;
+  }
+  const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
+  for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // finite everywhere (rows with weight 0)
+  __syncthreads();
+  const int PE = TS / 2;  // sample pairs per chunk
+
+  for (;;) {
+    if (tid == 0) shi[0] = atomicAdd(A.work_counter, 1);
+    __syncthreads();
+    const int f = shi[0];
+    __syncthreads();
+    if (f >= A.n_frames) break;
+    const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
+    const int N = 2 * wl + 1, mid = wl;
+    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
+    const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc, ldl = M + 1;
+    const int nb = (C1 + 15) >> 4, C1p = nb << 4;
+    if (nb < min_nb) continue;                   // small frames were done by eaqhm_ls_tile_kernel
+    const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
+    const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
+    const int npass = (units + MF_WAVES * MF_NSLOT - 1) / (MF_WAVES * MF_NSLOT);
+    const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
+    const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
+    const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
+
+    if (A.mode == 1) fill_columns(A, S.Q, S.r, rho, mycols, n, N, mid, c, wl, seeds);
+    // padding columns of this frame must be zero
+    for (int q = tid; q < TS * (C1p - C1); q += nt) {
+      int row = q / (C1p - C1), col = C1 + q - row * (C1p - C1);
+      Xre[row * ldx + col] = 0.0;
+      Xim[row * ldx + col] = 0.0;
+    }
+    __syncthreads();
+
+    for (int pass = 0; pass < npass; ++pass) {
+      d4 accR[MF_NSLOT], accI[MF_NSLOT];
+      int tI[MF_NSLOT], tJ[MF_NSLOT], wsel[MF_NSLOT];
+      bool live[MF_NSLOT];
+#pragma unroll
+      for (int sl = 0; sl < MF_NSLOT; ++sl) {
+        accR[sl] = (d4){0, 0, 0, 0};
+        accI[sl] = (d4){0, 0, 0, 0};
+        const int x = (pass * MF_NSLOT + sl) * MF_WAVES + wave;
+        live[sl] = x < units;
+        int I = 0, J = 0;
+        tile_of(live[sl] ? x / 3 : 0, I, J);
+        tI[sl] = I; tJ[sl] = J;
+        wsel[sl] = live[sl] ? x % 3 : 0;
+      }
+
+      for (int e0 = 0; e0 < npairs; e0 += PE) {
+        // ---- build the chunk: rows 2*el (sample u = e-1) and 2*el+1 (sample v = N-1-e)
+#pragma clang loop unroll(disable)
+        for (int idx = tid; idx < PE * n; idx += nt) {
+          const int el = idx / n, j = idx - el * n, e = e0 + el;
+          if (e >= npairs) continue;
+          const int u = e - 1, v = N - 1 - e;
+          double su, cu, sv, cv, ru = 1.0, ru1 = 1.0, rv = 1.0, rv1 = 1.0, pr = 1.0, pi = 0.0;
+          if (A.mode == 1) {
+            sincos_cw((2.0 * M_PI * S.Q[(size_t)(u + 1) * n + j]) / A.fs, &su, &cu);
+            sincos_cw((2.0 * M_PI * S.Q[(size_t)(v + 1) * n + j]) / A.fs, &sv, &cv);
+            if (u >= 0) { ru = S.r[(size_t)u * n + j]; rv1 = S.r[(size_t)(v + 1) * n + j]; }
+            ru1 = S.r[(size_t)(u + 1) * n + j];
+            rv = S.r[(size_t)v * n + j];
+            pr = rho[2 * j]; pi = rho[2 * j + 1];
+            // positive column at t uses E1(t); negative column at t uses r[mirror+1] * E1(mirror) * rho
+            double* xr = Xre + (2 * el) * ldx;
+            double* xi = Xim + (2 * el) * ldx;
+            if (u >= 0) {
+              xr[n + 1 + j] = ru * cu;                  xi[n + 1 + j] = ru * su;
+              xr[j] = rv1 * (cv * pr - sv * pi);        xi[j] = rv1 * (cv * pi + sv * pr);
+            }
+            xr += ldx; xi += ldx;
+            xr[n + 1 + j] = rv * cv;                    xi[n + 1 + j] = rv * sv;
+            xr[j] = ru1 * (cu * pr - su * pi);          xi[j] = ru1 * (cu * pi + su * pr);
+          } else {
+            const double fk = (double)(j + 1) * f0;
+            double* xr = Xre + (2 * el) * ldx;
+            double* xi = Xim + (2 * el) * ldx;
+            if (u >= 0) {
+              sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
+              xr[n + 1 + j] = cu; xi[n + 1 + j] = su; xr[j] = cu; xi[j] = -su;
+            }
+            sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
+            xr += ldx; xi += ldx;
+            xr[n + 1 + j] = cv; xi[n + 1 + j] = sv; xr[j] = cv; xi[j] = -sv;
+          }
+        }
+#pragma clang loop unroll(disable)
+        for (int row = tid; row < TS; row += nt) {
+          const int e = e0 + (row >> 1);
+          const int t = (row & 1) ? (N - 1 - e) : (e - 1);
+          double w0 = 0.0, sv = 0.0;
+          if (e < npairs && t >= 0) {
+            double w = window_value(A.mode == 0, t, N);
+            w0 = w * w;
+            sv = A.s[(size_t)(c - wl) + t];
+          }
+          const double nn = (double)(t - mid);
+          Wp[row] = w0; Wp[TS + row] = w0 * nn; Wp[2 * TS + row] = w0 * nn * nn;
+          Xre[row * ldx + n] = 1.0;  Xim[row * ldx + n] = 0.0;   // DC column
+          Xre[row * ldx + Kc] = sv;  Xim[row * ldx + Kc] = 0.0;  // signal column
+        }
+        __syncthreads();
+        // ---- contraction of the chunk
+        const int lbase = (lane >> 4) * ldx + (lane & 15);
+#pragma unroll
+        for (int sl = 0; sl < MF_NSLOT; ++sl) {
+          if (!live[sl]) continue;
+          const double* wrow = Wp + wsel[sl] * TS + (lane >> 4);
+          const double* pAr = Xre + lbase + 16 * tI[sl];
+          const double* pAi = Xim + lbase + 16 * tI[sl];
+          const double* pBr = Xre + lbase + 16 * tJ[sl];
+          const double* pBi = Xim + lbase + 16 * tJ[sl];
+#pragma clang loop unroll(disable)
+          for (int ks = 0; ks < TS / 4; ++ks) {
+            const int ro = 4 * ks * ldx;
+            const double aR = pAr[ro], aI = pAi[ro];
+            const double w = wrow[4 * ks];
+            const double bR = w * pBr[ro], bI = w * pBi[ro];
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+
+      // ---- accumulators -> transposed system matrix Lt[col][row] (R = [[G0,G1],[G1,G2]], RHS row M)
+#pragma unroll
+      for (int sl = 0; sl < MF_NSLOT; ++sl) {
+        if (!live[sl]) continue;
+        const int I = tI[sl], J = tJ[sl], p = wsel[sl];
+        const int b = 16 * J + (lane & 15);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int a = 16 * I + (lane >> 4) + 4 * rr;
+          const double gr = accR[sl][rr], gi = accI[sl][rr];
+          auto put = [&](int row, int col, double re, double im) {
+            size_t o = ((size_t)col * ldl + row) * 2;
+            S.Lt[o] = re; S.Lt[o + 1] = im;
+          };
+          if (b >= Kc) continue;
+          if (a < Kc) {
+            if (p == 0) { if (a >= b) put(a, b, gr, gi); }
+            else if (p == 2) { if (a >= b) put(Kc + a, Kc + b, gr, gi); }
+            else {
+              put(Kc + a, b, gr, gi);
+              if (I != J) put(Kc + b, a, gr, -gi);
+            }
+          } else if (a == Kc) {  // signal row: conj(rhs) (see gram_to_system in eaqhm_ls.hip)
+            if (p == 0) put(M, b, gr, gi);
+            else if (p == 1) put(M, Kc + b, gr, gi);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    cholesky_solve(S.Lt, M, ldl, rowj, xs, sh);
+    write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
+  }
+}
+
+size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax) {
+  return (mf_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
+}
+
+// A.scratch / A.scratch_stride / A.work_counter are set by the caller (eaqhm_ls_batch)
+int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
+  const int nmax = A.nmax, Kcmax = A.Kcmax;
+  const int nbmax = (Kcmax + 1 + 15) / 16;
+  const int ldx_max = 16 * nbmax + 16;
+  const size_t fixed = (size_t)(2 * nmax + 4 * (2 * Kcmax) + 16) * sizeof(double);
+  int TS = 32;
+  while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 150 * 1024) TS >>= 1;
+  const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
+  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, min_nb);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}
+
+}  // namespace eaqhm

@@ -19,6 +19,7 @@ SYMBOLS = (
     ("eaqhm_set_stream", C.c_int, [_P, _P]),
     ("eaqhm_sync", C.c_int, [_P]),
     ("eaqhm_last_error", C.c_char_p, [_P]),
+    ("eaqhm_set_option", C.c_int, [_P, _I32, _I32]),
     ("eaqhm_device_info", C.c_int, [_P, C.POINTER(_I32)]),
     ("eaqhm_frame_prep", C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
     ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -90,6 +91,9 @@ class Context:
         info = (_I32 * 4)()
         self._ck(self.lib.eaqhm_device_info(self.h, info))
         self.n_cu, self.lds_bytes, self.clock_khz, self.abi_version = [int(v) for v in info]
+        v = os.environ.get("EAQHM_LS_VARIANT")          # A/B knob for measurements (include/eaqhm_hip.h)
+        if v:
+            self.set_option(1, int(v))
         self.bind_stream()
 
     def bind_stream(self):
@@ -111,6 +115,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key, value):
+        self._ck(self.lib.eaqhm_set_option(self.h, key, value))
 
     def sync(self):
         self._ck(self.lib.eaqhm_sync(self.h))

@@ -49,6 +49,12 @@ int eaqhm_ctx_destroy(eaqhm_ctx* ctx);
 int eaqhm_set_stream(eaqhm_ctx* ctx, void* hip_stream);
 int eaqhm_sync(eaqhm_ctx* ctx);
 const char* eaqhm_last_error(eaqhm_ctx* ctx);
+/* tuning knobs (for A/B measurements; defaults are the fastest validated choice)
+ *   EAQHM_OPT_LS_VARIANT: 1 = VALU Gramian + scratch Cholesky (any size), 2 = MFMA Gramian + scratch Cholesky,
+ *                         3 = Gramian and tile Cholesky on chip for frames of <= 6 column blocks, 2 for the rest
+ *                             (default) */
+#define EAQHM_OPT_LS_VARIANT 1
+int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value);
 /* library / device facts: fills {n_cu, lds_bytes, clock_khz, abi_version} */
 int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
 
