@@ -57,5 +57,19 @@ extern "C" int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value) {
     ctx->ls_variant = value;
     return EAQHM_OK;
   }
+  if (key == EAQHM_OPT_DEBUG_KEEP) {
+    ctx->dbg_keep = value;
+    if (value && ctx->scratch && ctx->scratch_bytes >= 256)
+      (void)hipMemsetAsync((char*)ctx->scratch + ctx->scratch_bytes - 256 + 64, 0, 128, ctx->stream);
+    return EAQHM_OK;
+  }
   return ctx->fail(EAQHM_EINVAL, "eaqhm_set_option: unknown key or value");
+}
+
+extern "C" int eaqhm_debug_read(eaqhm_ctx* ctx, uint64_t h_out[16]) {
+  if (!ctx || !h_out) return EAQHM_EINVAL;
+  if (!ctx->scratch || ctx->scratch_bytes < 256) return ctx->fail(EAQHM_EINVAL, "eaqhm_debug_read: nothing to read");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(h_out, (char*)ctx->scratch + ctx->scratch_bytes - 256 + 64, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return EAQHM_OK;
 }

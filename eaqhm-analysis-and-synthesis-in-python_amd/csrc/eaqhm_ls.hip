@@ -20,6 +20,7 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb);  // eaqhm_ls
 size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax);
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid);              // eaqhm_ls_tile.hip
 size_t ls_tile_scratch_stride(int nmax, int Nmax);
+bool ls_tile_applicable(int Kcmax, int Nmax);
 
 
 // ------------------------------------------------------------------------------------------------
@@ -309,10 +310,11 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
     int rc = ctx->reserve((st_m > st_t ? st_m : st_t) * grid * sizeof(double) + 256);
     if (rc) return rc;
     int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 2 * sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
+    B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
     B.scratch = (double*)ctx->scratch;
     int min_nb = 0;
-    if (ctx->ls_variant == 3) {   // small frames: everything in registers/LDS; the rest falls through
+    if (ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax)) {   // small frames: everything in registers/LDS; the rest falls through
       B.scratch_stride = st_t; B.work_counter = counters;
       rc = launch_ls_tile(ctx, B, grid);
       if (rc) return rc;
@@ -333,7 +335,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
   A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
   A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
-  A.Kcmax = Kcmax; A.work_counter = nullptr;
+  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr;
   size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -16,7 +16,8 @@ struct LsArgs {
   int n_frames; int a_iter; double f0_stale; double f0min;
   double* records; double* raw_amp; double* raw_slope;
   double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
-  int* work_counter;  // dynamic frame queue (v2); may be null
+  int* work_counter;  // dynamic frame queue; may be null
+  unsigned long long* debug;  // phase stamps (16 x u64)
 };
 
 // seed-aware track access (functions.py:209-210; see eaqhm_frame_prep): a seeded row shows 140 Hz / 10e-4

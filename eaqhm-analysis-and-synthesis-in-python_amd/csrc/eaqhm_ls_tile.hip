@@ -1,7 +1,9 @@
 // eaqhm_ls_tile.hip — the per-frame LS entirely on chip: Gramian AND factorisation on the FP64 matrix cores,
 // the system matrix never leaves the register file (gfx950).
 //
-// A workgroup of 512 threads (8 waves, 2 per SIMD) owns one frame at a time (atomic frame queue).
+// A workgroup of 512 threads owns one frame at a time (atomic frame queue): 7 compute waves that own the
+// system tiles in their registers, and 1 specialist wave that factorises the diagonal tiles (its register
+// file is free of accumulators, so the serial 16-column chain runs without spills).
 //
 // Unknown ordering.  The basis columns are cut into nb blocks of 16 ([negative | DC | positive | signal | 0-pad]).
 // Unknowns are ordered block by block, amplitudes (alpha=0) then slopes (alpha=1) of each block, except that
@@ -9,13 +11,17 @@
 // so its row of the Hermitian system is the last real row: factorising the matrix WITH that row/column leaves
 // conj(L^-1 rhs) in it — the forward substitution costs nothing.  System tile (P,Q) = G_{alpha_P+alpha_Q}[I_P][I_Q]
 // with G_p = X^H diag(w^2 n^p) X: every 16x16 complex system tile is one MFMA accumulation over time, owned by
-// one wave (tile x = P(P+1)/2+Q -> wave x%8, slot x/8) from the first sample to the last back-substitution step.
+// one compute wave (tile x = P(P+1)/2+Q -> wave x%7, slot x/7) from the first sample to the last
+// back-substitution step.
 //
-//   A1     slot windows, gap fill, running sums (eaqhm_ls_common.h)                      -> global scratch
-//   A3+B   chunks of 16 sample pairs built in LDS by all threads, contracted by MFMA (see eaqhm_ls_mfma.hip)
-//   C      right-looking tile Cholesky: the diagonal tile is factorised AND inverted in registers by its owner
-//          (wave shuffles), panel tiles are multiplied by the inverse (MFMA) and published in LDS, trailing
-//          tiles are updated from LDS operands (MFMA).  Two barriers per panel; no global memory traffic.
+//   A1     one wave per (slot, 64-sample chunk): coalesced track windows, gaps found with ballots and bridged,
+//          wave scan of fm                                                                  -> global scratch
+//   A3+B   chunks of 16 sample PAIRS (u, N-2-u) built in LDS by all threads — the pair shares its sincos
+//          because the negative-frequency column at u is the time-reversed positive one (functions.py:284-285)
+//          — and contracted with v_mfma_f64_16x16x4_f64 (4 real MFMAs per k-step and tile)
+//   C      right-looking tile Cholesky: diagonal tile -> LDS -> specialist wave factorises AND inverts it,
+//          panel tiles are multiplied by the inverse (MFMA) and published in LDS, trailing tiles are updated
+//          from LDS operands (MFMA).  Three barriers per panel; no global memory traffic.
 //   C'     back substitution from the L tiles still sitting in the owners' registers; z, x vectors in LDS
 //   D      frequency mismatch, acceptance, record row (eaqhm_ls_common.h)
 //
@@ -29,11 +35,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define TL_THREADS 512
 #define TL_WAVES 8
-#define TL_NS 10        // system tiles per wave: 80 >= 78 = nt(nt+1)/2 for nt = 12 (nb = 6)
+#define TL_CW 8         // all waves own tiles
 #define TL_NBMAX 6
 #define TL_NTMAX 12
 #define TL_LD 17        // tile row stride in LDS (doubles): conflict-free transposing stores
 #define TL_TILE (16 * TL_LD)
+#define CI_STRIDE 20    // per-slot info: 16 chunk carries, qmid, 1/(am_mid+eps), rho.re, rho.im
+#define CI_NCH 16
+#define XCOL(cc, el) (((cc) & ~15) | (((cc) + (el)) & 15))
 
 __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   P = (int)((sqrtf(8.0f * (float)x + 1.0f) - 1.0f) * 0.5f);
@@ -47,60 +56,159 @@ __device__ inline void block_of(int P, int nt, int& I, int& alpha) {
   else { I = (nt >> 1) - 1; alpha = (P == nt - 2) ? 1 : 0; }
 }
 
-__device__ inline double shfl_d(double v, int src) { return __shfl(v, src, 64); }
-
-// Cholesky factor L and its inverse W of a 16x16 Hermitian positive definite tile held in MFMA accumulator
-// layout (lane: col = l&15, rows (l>>4)+4r).  By symmetry the same registers read as
-// D[i][k] = conj(acc[r]) with i = l&15, k = (l>>4)+4r.  Outputs in that (row i, column k) layout.
-__device__ inline void factor_diag(const d4& aR, const d4& aI, double (&Lr)[4], double (&Li)[4], double (&Wr)[4],
-                                   double (&Wi)[4], int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    Lr[m] = aR[m]; Li[m] = -aI[m];
-    Wr[m] = (i == kq + 4 * m) ? 1.0 : 0.0; Wi[m] = 0.0;
+// ---- Phase A1 -----------------------------------------------------------------------------------------------
+//   Qloc[j][t]  scan of fm inside its 64-sample chunk         (global scratch, row stride Npad)
+//   Af[j][t]    gap-filled am                                  (global scratch)
+//   ci          per-slot info in LDS, so that  F(u) - F(mid) = Qloc[j][u] + carry[j][u>>6] - qmid[j]
+//               and  ratio(u) = (eps + Af[j][u]) * ainv[j]      (functions.py:508-518)
+__device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* Af, int Npad, double* ci,
+                                        unsigned long long* masks, const int* mycols, int n, int N, int mid, int c,
+                                        int wl, bool seeds, int lane, int wave) {
+  const double eps = 10e-5;  // functions.py:517
+  const int nch = (N + 63) >> 6;
+  const long long t0 = (long long)c - wl;
+  for (int it = wave; it < n * nch; it += TL_WAVES) {  // pass 1: nonzero masks of every (slot, chunk)
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+    const double f = (t < N) ? track_fm(A, mycols[j], t0 + t, c, seeds) : 0.0;
+    const unsigned long long m = __ballot(f != 0.0);
+    if (lane == 0) masks[j * CI_NCH + ch] = m;
   }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int mj = j >> 2, qj = j & 3;
-    double piv = shfl_d(Lr[mj], j + 16 * qj);
-    piv = (piv > 0.0) ? piv : 1.0;  // only the RHS position of the last tile can get here (residual energy ~ 0)
-    const double dinv = 1.0 / sqrt(piv);
-    if (kq == qj) {  // column j: scale below the diagonal, clean above
-      if (i > j) { Lr[mj] *= dinv; Li[mj] *= dinv; }
-      else if (i == j) { Lr[mj] = piv * dinv; Li[mj] = 0.0; }
-      else { Lr[mj] = 0.0; Li[mj] = 0.0; }
+  __syncthreads();
+  for (int it = wave; it < n * nch; it += TL_WAVES) {  // pass 2: fill, scan, store
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+    const int k = mycols[j];
+    double f = 0.0, a = 0.0;
+    if (t < N) {
+      f = track_fm(A, k, t0 + t, c, seeds);
+      a = track_am(A, k, t0 + t, c, seeds);
+      if (f == 0.0) {  // nearest nonzero samples on both sides, from the masks (functions.py:251-278)
+        int p = -1, q = -1;
+        {
+          unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+          int cc = ch;
+          while (m == 0ull && cc > 0) { --cc; m = masks[j * CI_NCH + cc]; }
+          if (m != 0ull) p = (cc << 6) + 63 - __clzll((long long)m);
+        }
+        {
+          unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
+          int cc = ch;
+          while (m == 0ull && cc < nch - 1) { ++cc; m = masks[j * CI_NCH + cc]; }
+          if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
+        }
+        if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
+          f = track_fm(A, k, t0 + q, c, seeds); a = track_am(A, k, t0 + q, c, seeds);
+        } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
+          f = track_fm(A, k, t0 + p, c, seeds); a = track_am(A, k, t0 + p, c, seeds);
+        } else {             // interior gap: linear (functions.py:277-278)
+          const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
+          const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
+          const double dx = (double)(q - p), xx = (double)(t - p);
+          f = ((f1v - f0v) / dx) * xx + f0v;
+          a = ((a1v - a0v) / dx) * xx + a0v;
+        }
+      }
     }
-    const double lijr = shfl_d(Lr[mj], i + 16 * qj), liji = shfl_d(Li[mj], i + 16 * qj);  // L[i][j]
+    double sc = f;  // inclusive scan over the wave
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int k = kq + 4 * m;
-      const double lkr = shfl_d(Lr[mj], k + 16 * qj), lki = shfl_d(Li[mj], k + 16 * qj);  // L[k][j]
-      if (k > j && i >= k) {  // D[i][k] -= L[i][j] conj(L[k][j])
-        Lr[m] -= lijr * lkr + liji * lki;
-        Li[m] -= liji * lkr - lijr * lki;
-      }
-      // inverse by forward elimination on [L | I]: row j /= L[j][j]; rows i > j -= L[i][j] * row j
-      const double zr = shfl_d(Wr[m], j + 16 * kq) * dinv, zi = shfl_d(Wi[m], j + 16 * kq) * dinv;
-      if (i == j) { Wr[m] = zr; Wi[m] = zi; }
-      else if (i > j) {
-        Wr[m] -= lijr * zr - liji * zi;
-        Wi[m] -= lijr * zi + liji * zr;
-      }
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(sc, o, 64);
+      if (lane >= o) sc += up;
+    }
+    if (t < N) {
+      Qloc[(size_t)j * Npad + t] = sc;
+      Af[(size_t)j * Npad + t] = a;
+    }
+    if (lane == 63) ci[j * CI_STRIDE + ch] = sc;  // chunk total (turned into carries below)
+    if (t == mid) {
+      ci[j * CI_STRIDE + 16] = sc;                // local scan at mid (carry added below)
+      ci[j * CI_STRIDE + 17] = 1.0 / (a + eps);
+      double sn, cs;
+      sincos_cw((2.0 * M_PI * f) / A.fs, &sn, &cs);
+      ci[j * CI_STRIDE + 18] = cs;
+      ci[j * CI_STRIDE + 19] = sn;
     }
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    double run = 0.0;
+    for (int ch = 0; ch < nch; ++ch) {
+      const double tot = ci[j * CI_STRIDE + ch];
+      ci[j * CI_STRIDE + ch] = run;
+      run += tot;
+    }
+    ci[j * CI_STRIDE + 16] += ci[j * CI_STRIDE + (mid >> 6)];
+  }
+  __syncthreads();
 }
 
-extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max) {
+// ---- diagonal tile: Cholesky factor L and W = L^-1 of a 16x16 Hermitian positive definite tile, by the whole
+// workgroup.  The sixteen column steps are a serial chain on the critical path of the frame, so each step is
+// made as short as possible: one thread per matrix entry (threads 0-255: D, threads 256-511: the inverse by
+// forward elimination on [L | I]), three LDS reads, one reciprocal, one complex multiply-add, one barrier.
+//   D  [16][16] complex (interleaved), row-major, lower triangle used;  Z likewise (starts as identity)
+//   outputs: Wt planes hold (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j];  Ld planes hold L[i][j] at [i*TL_LD + j]
+__device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
+  const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
+  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
+  __syncthreads();
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < 15; ++j) {   // after step j, column j of D and row j of Z are final (still unscaled)
+    const bool work = (g == 0) ? (k > j && i >= k) : (i > j && k <= j);
+    if (work) {
+      double piv = D[2 * (j * 16 + j)];
+      piv = (piv > 0.0) ? piv : 1.0;  // only the RHS position of the last tile can get here (residual ~ 0)
+      double rinv = __builtin_amdgcn_rcp(piv);  // 1/piv, two Newton steps
+      rinv = rinv * fma(-piv, rinv, 2.0);
+      rinv = rinv * fma(-piv, rinv, 2.0);
+      const double ar = D[2 * (i * 16 + j)], ai = D[2 * (i * 16 + j) + 1];  // D[i][j] = L[i][j] L[j][j]
+      if (g == 0) {  // D[i][k] -= D[i][j] conj(D[k][j]) / piv
+        const double br = D[2 * (k * 16 + j)], bi = D[2 * (k * 16 + j) + 1];
+        D[2 * e] -= (ar * br + ai * bi) * rinv;
+        D[2 * e + 1] -= (ai * br - ar * bi) * rinv;
+      } else {       // Z[i][k] -= D[i][j] Z[j][k] / piv
+        const double zr = Z[2 * (j * 16 + k)], zi = Z[2 * (j * 16 + k) + 1];
+        Z[2 * e] -= (ar * zr - ai * zi) * rinv;
+        Z[2 * e + 1] -= (ar * zi + ai * zr) * rinv;
+      }
+    }
+    __syncthreads();
+  }
+  // scale: L[i][j] = D[i][j] / sqrt(piv_j) (column j), W[i][k] = Z[i][k] / sqrt(piv_i) (row i)
+  {
+    const int pj = (g == 0) ? k : i;
+    double piv = D[2 * (pj * 16 + pj)];
+    piv = (piv > 0.0) ? piv : 1.0;
+    double dinv = __builtin_amdgcn_rsq(piv);
+    dinv = dinv * fma(-0.5 * piv * dinv, dinv, 1.5);
+    dinv = dinv * fma(-0.5 * piv * dinv, dinv, 1.5);
+    if (g == 0) {
+      const double vr = D[2 * e], vi = D[2 * e + 1];
+      LdR[i * TL_LD + k] = (i > k) ? vr * dinv : ((i == k) ? piv * dinv : 0.0);
+      LdI[i * TL_LD + k] = (i > k) ? vi * dinv : 0.0;
+    } else {  // stored as (W^H)[k][i] = conj(W[i][k])
+      const double zr = (k <= i) ? Z[2 * e] : 0.0, zi = (k <= i) ? Z[2 * e + 1] : 0.0;
+      WtR[k * TL_LD + i] = zr * dinv;
+      WtI[k * TL_LD + i] = -zi * dinv;
+    }
+  }
+  __syncthreads();
+}
+
+template <int NS>
+__global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max, int nb_lo, int nb_hi) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- LDS carve-up: region U is used as the basis chunk in the Gramian phase and as tile storage afterwards
+  const bool spec = false;
+  // ---- LDS carve-up: region U is the basis chunk (+ slot info) in the Gramian phase, tile storage afterwards
   double* U = lds;
   double* Xre = U;
   double* Xim = Xre + (size_t)TS * ldx_max;
-  double* Wp = Xim + (size_t)TS * ldx_max;  // 3*TS
+  double* Wp = Xim + (size_t)TS * ldx_max;           // 3*TS  weights w^2 n^p per chunk row
+  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS;
+  double* ci = U + usize_g;                          // [48][CI_STRIDE]
+  unsigned long long* masks = (unsigned long long*)(ci + (size_t)CI_STRIDE * 48);  // [48][16]
   double* PanR = U;                                  // [NT][TILE]  published panel tiles, [k][row]
   double* PanI = PanR + TL_NTMAX * TL_TILE;
   double* WtR = PanI + TL_NTMAX * TL_TILE;           // [NT][TILE]  (W^H)[k][j] of every diagonal tile
@@ -109,20 +217,31 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
   double* TmpI = TmpR + TL_WAVES * TL_TILE;
   double* LdR = TmpI + TL_WAVES * TL_TILE;           // [TILE]      last diagonal factor, [row][col]
   double* LdI = LdR + TL_TILE;
-  double* zv = LdI + TL_TILE;                        // 2*16*NT
+  double* Dc = LdI + TL_TILE;                        // [512]       diagonal tile being factorised (complex, row-major)
+  double* Zc = Dc + 512;                             // [512]       its inverse in the making
+  double* zv = Zc + 512;                        // 2*16*NT
   double* xv = zv + 2 * 16 * TL_NTMAX;               // 2*16
   const size_t usize_c = (size_t)(xv + 32 - U);
-  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS;
-  double* rho = U + (usize_c > usize_g ? usize_c : usize_g);  // 2*nmax
-  double* xs = rho + 2 * A.nmax;                     // 2*Mmax
+  double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
   double* sh = xs + 4 * A.Kcmax;                     // 16
   int* shi = (int*)(sh + 12);
 
-  double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
-  double* Rs = Qs + (size_t)(A.Nmax + 1) * A.nmax;
+  const int Npad = ((A.Nmax + 63) >> 6) << 6;
+  double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
+  double* Rs = Qs + (size_t)Npad * A.nmax;                         // Af[j][t]
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
   const int PE = TS / 2;
   const int lcol = lane & 15, lq = lane >> 4;
+  unsigned long long* dbg = A.debug;
+  unsigned long long t_prev = 0;
+#define STAMP(ph)                                                   \
+  do {                                                              \
+    if (dbg && tid == 0) {                                          \
+      unsigned long long t_now = __builtin_amdgcn_s_memtime();      \
+      atomicAdd(dbg + (ph), t_now - t_prev);                        \
+      t_prev = t_now;                                               \
+    }                                                               \
+  } while (0)
 
   for (;;) {
     if (tid == 0) shi[0] = atomicAdd(A.work_counter, 1);
@@ -133,31 +252,34 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
     const int Kc = 2 * n + 1, C1 = Kc + 1;
     const int nb = (C1 + 15) >> 4;
-    if (nb > TL_NBMAX) continue;  // left to eaqhm_ls_mfma_kernel
+    if (nb < nb_lo || nb > nb_hi) continue;  // another instantiation (or eaqhm_ls_mfma_kernel) owns this frame
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
     const int N = 2 * wl + 1, mid = wl;
     const int C1p = nb << 4;
-    const int ldx = C1p + ((nb & 1) ? 0 : 16);
+    const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
     const int nt = 2 * nb, ntiles = nt * (nt + 1) / 2;
     const int is = Kc - 16 * (nb - 1);  // position of the signal column inside the last block (1..15)
     const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
-    const int npairs = mid + 1;
+    const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 
+    if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
     for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
-    if (A.mode == 1) fill_columns(A, Qs, Rs, rho, mycols, n, N, mid, c, wl, seeds);
     __syncthreads();
+    if (A.mode == 1) fill_columns_par(A, Qs, Rs, Npad, ci, masks, mycols, n, N, mid, c, wl, seeds, lane, wave);
+    STAMP(0);
 
-    d4 accR[TL_NS], accI[TL_NS];
-    int tP[TL_NS], tQ[TL_NS];
-    bool live[TL_NS];
+    // system tiles of this wave (compute waves only)
+    d4 accR[NS], accI[NS];
+    int tP[NS], tQ[NS];
+    bool live[NS];
 #pragma unroll
-    for (int sl = 0; sl < TL_NS; ++sl) {
+    for (int sl = 0; sl < NS; ++sl) {
       accR[sl] = (d4){0, 0, 0, 0};
       accI[sl] = (d4){0, 0, 0, 0};
-      const int x = sl * TL_WAVES + wave;
-      live[sl] = x < ntiles;
+      const int x = sl * TL_CW + wave;
+      live[sl] = (!spec) && (x < ntiles);
       int P = 0, Q = 0;
       sys_tile_of(live[sl] ? x : 0, P, Q);
       tP[sl] = P; tQ[sl] = Q;
@@ -165,36 +287,46 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
 
     // ================= Gramian =================
     for (int e0 = 0; e0 < npairs; e0 += PE) {
+      // logical column cc of chunk rows (2*el, 2*el+1) lives at XCOL(cc, el): the 16 lanes that write one column
+      // of 16 different pairs hit 16 different banks, and MFMA operand reads stay conflict-free
 #pragma clang loop unroll(disable)
-      for (int idx = tid; idx < PE * n; idx += nt_thr) {
-        const int el = idx / n, j = idx - el * n, e = e0 + el;
-        if (e >= npairs) continue;
+      for (int idx = tid; idx < 16 * n; idx += nt_thr) {
+        const int el = idx & 15, j = idx >> 4, e = e0 + el;
+        if (e >= npairs || el >= PE) continue;
         const int u = e - 1, v = N - 1 - e;
         double su = 0, cu = 1, sv, cv;
         double* xr = Xre + (2 * el) * ldx;
         double* xi = Xim + (2 * el) * ldx;
+        const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);
         if (A.mode == 1) {
-          sincos_cw((2.0 * M_PI * Qs[(size_t)(u + 1) * n + j]) / A.fs, &su, &cu);
-          sincos_cw((2.0 * M_PI * Qs[(size_t)(v + 1) * n + j]) / A.fs, &sv, &cv);
-          const double pr = rho[2 * j], pi = rho[2 * j + 1];
+          const double* cj = ci + j * CI_STRIDE;
+          const double qmid = cj[16], ainv = cj[17], pr = cj[18], pi = cj[19];
+          const double* ql = Qs + (size_t)j * Npad;
+          const double* af = Rs + (size_t)j * Npad;
+          const double qu = (u >= 0) ? (ql[u] + cj[u >> 6] - qmid) : -qmid;
+          const double qv = ql[v] + cj[v >> 6] - qmid;
+          sincos_cw((2.0 * M_PI * qu) / A.fs, &su, &cu);
+          sincos_cw((2.0 * M_PI * qv) / A.fs, &sv, &cv);
+          const double eps = 10e-5;
+          // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
           if (u >= 0) {
-            const double ru = Rs[(size_t)u * n + j], rv1 = Rs[(size_t)(v + 1) * n + j];
-            xr[n + 1 + j] = ru * cu;               xi[n + 1 + j] = ru * su;
-            xr[j] = rv1 * (cv * pr - sv * pi);     xi[j] = rv1 * (cv * pi + sv * pr);
+            const double ru = (eps + af[u]) * ainv, rv1 = (eps + af[v + 1]) * ainv;
+            xr[cpos] = ru * cu;                    xi[cpos] = ru * su;
+            xr[cneg] = rv1 * (cv * pr - sv * pi);  xi[cneg] = rv1 * (cv * pi + sv * pr);
           }
-          const double rv = Rs[(size_t)v * n + j], ru1 = Rs[(size_t)(u + 1) * n + j];
+          const double rv = (eps + af[v]) * ainv, ru1 = (eps + af[u + 1]) * ainv;
           xr += ldx; xi += ldx;
-          xr[n + 1 + j] = rv * cv;                 xi[n + 1 + j] = rv * sv;
-          xr[j] = ru1 * (cu * pr - su * pi);       xi[j] = ru1 * (cu * pi + su * pr);
-        } else {
+          xr[cpos] = rv * cv;                      xi[cpos] = rv * sv;
+          xr[cneg] = ru1 * (cu * pr - su * pi);    xi[cneg] = ru1 * (cu * pi + su * pr);
+        } else {  // adaptation 0: exp(j 2 pi k f0 n / fs), negative column = conjugate (functions.py:453-454)
           const double fk = (double)(j + 1) * f0;
           if (u >= 0) {
             sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
-            xr[n + 1 + j] = cu; xi[n + 1 + j] = su; xr[j] = cu; xi[j] = -su;
+            xr[cpos] = cu; xi[cpos] = su; xr[cneg] = cu; xi[cneg] = -su;
           }
           sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
           xr += ldx; xi += ldx;
-          xr[n + 1 + j] = cv; xi[n + 1 + j] = sv; xr[j] = cv; xi[j] = -sv;
+          xr[cpos] = cv; xi[cpos] = sv; xr[cneg] = cv; xi[cneg] = -sv;
         }
       }
 #pragma clang loop unroll(disable)
@@ -209,28 +341,27 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
         }
         const double nn = (double)(t - mid);
         Wp[row] = w0; Wp[TS + row] = w0 * nn; Wp[2 * TS + row] = w0 * nn * nn;
-        Xre[row * ldx + n] = 1.0;   Xim[row * ldx + n] = 0.0;
-        Xre[row * ldx + Kc] = sval; Xim[row * ldx + Kc] = 0.0;
+        const int el = row >> 1;
+        Xre[row * ldx + XCOL(n, el)] = 1.0;    Xim[row * ldx + XCOL(n, el)] = 0.0;   // DC column
+        Xre[row * ldx + XCOL(Kc, el)] = sval;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
       }
       __syncthreads();
-      const int lbase = lq * ldx + lcol;
+      STAMP(1);
 #pragma unroll
-      for (int sl = 0; sl < TL_NS; ++sl) {
+      for (int sl = 0; sl < NS; ++sl) {
         if (!live[sl]) continue;
         int Ia, aa, Ib, ab;
         block_of(tP[sl], nt, Ia, aa);
         block_of(tQ[sl], nt, Ib, ab);
         const double* wrow = Wp + (aa + ab) * TS + lq;
-        const double* pAr = Xre + lbase + 16 * Ia;
-        const double* pAi = Xim + lbase + 16 * Ia;
-        const double* pBr = Xre + lbase + 16 * Ib;
-        const double* pBi = Xim + lbase + 16 * Ib;
 #pragma clang loop unroll(disable)
         for (int ks = 0; ks < TS / 4; ++ks) {
-          const int ro = 4 * ks * ldx;
-          const double aR = pAr[ro], aI = pAi[ro];
+          const int row = 4 * ks + lq;
+          const int sw = (lcol + (row >> 1)) & 15;
+          const int oa = row * ldx + 16 * Ia + sw, ob = row * ldx + 16 * Ib + sw;
+          const double aR = Xre[oa], aI = Xim[oa];
           const double w = wrow[4 * ks];
-          const double bR = w * pBr[ro], bI = w * pBi[ro];
+          const double bR = w * Xre[ob], bI = w * Xim[ob];
           accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
           accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
           accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
@@ -238,182 +369,206 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
         }
       }
       __syncthreads();
+      STAMP(2);
     }
 
-    // ---- neutralise dummy unknowns: in the last column block the positions >= is of the slope part (the
-    // signal column's slope + padding) and the positions > is of the amplitude part (padding) get an identity
-    // row/column; position `is` of the amplitude part is the RHS row/column and stays.
+    {
+      // ================= compute waves =================
+      // ---- neutralise dummy unknowns: in the last column block the positions >= is of the slope part (the
+      // signal column's slope + padding) and the positions > is of the amplitude part (padding) get an identity
+      // row/column; position `is` of the amplitude part is the RHS row/column and stays.
 #pragma unroll
-    for (int sl = 0; sl < TL_NS; ++sl) {
-      if (!live[sl]) continue;
-      const int P = tP[sl], Q = tQ[sl];
-      if (P < nt - 2) continue;
+      for (int sl = 0; sl < NS; ++sl) {
+        if (!live[sl]) continue;
+        const int P = tP[sl], Q = tQ[sl];
+        if (P < nt - 2) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lq + 4 * r, col = lcol;
-        const bool drow = (P == nt - 2) ? (row >= is) : (row > is);
-        const bool dcol = (Q == nt - 2) ? (col >= is) : ((Q == nt - 1) ? (col > is) : false);
-        if (drow || dcol) {
-          accR[sl][r] = (P == Q && row == col) ? 1.0 : 0.0;
-          accI[sl][r] = 0.0;
-        }
-      }
-    }
-
-    // ================= factorisation =================
-    for (int jb = 0; jb < nt; ++jb) {
-      const int xd = jb * (jb + 1) / 2 + jb;
-      if (wave == (xd & 7)) {
-        const int sd = xd >> 3;
-#pragma unroll
-        for (int sl = 0; sl < TL_NS; ++sl) {
-          if (sl != sd) continue;
-          double Lr[4], Li[4], Wr[4], Wi[4];
-          factor_diag(accR[sl], accI[sl], Lr, Li, Wr, Wi, lane);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int k = lq + 4 * m;  // column of L / W, row index is lcol
-            WtR[jb * TL_TILE + k * TL_LD + lcol] = Wr[m];
-            WtI[jb * TL_TILE + k * TL_LD + lcol] = -Wi[m];
-            LdR[lcol * TL_LD + k] = Lr[m];
-            LdI[lcol * TL_LD + k] = Li[m];
+        for (int r = 0; r < 4; ++r) {
+          const int row = lq + 4 * r, col = lcol;
+          const bool drow = (P == nt - 2) ? (row >= is) : (row > is);
+          const bool dcol = (Q == nt - 2) ? (col >= is) : ((Q == nt - 1) ? (col > is) : false);
+          if (drow || dcol) {
+            accR[sl][r] = (P == Q && row == col) ? 1.0 : 0.0;
+            accI[sl][r] = 0.0;
           }
         }
       }
-      __syncthreads();
-      // ---- panel tiles (P > jb, Q == jb): X = T W^H, published as Pan[P][k][row]
+      for (int jb = 0; jb < nt; ++jb) {
+        const int xd = jb * (jb + 1) / 2 + jb;
+        if (wave == (xd % TL_CW)) {  // hand the diagonal tile to the specialist: Dt[row][col] = T[row][col]
+          const int sd = xd / TL_CW;
 #pragma unroll
-      for (int sl = 0; sl < TL_NS; ++sl) {
-        if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
-        double* tr = TmpR + wave * TL_TILE;
-        double* ti = TmpI + wave * TL_TILE;
+          for (int sl = 0; sl < NS; ++sl)
+            if (sl == sd) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // T[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
-          tr[lcol * TL_LD + lq + 4 * r] = accR[sl][r];
-          ti[lcol * TL_LD + lq + 4 * r] = accI[sl][r];
+              for (int r = 0; r < 4; ++r) {
+                Dc[2 * ((lq + 4 * r) * 16 + lcol)] = accR[sl][r];
+                Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = accI[sl][r];
+              }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        d4 xr = (d4){0, 0, 0, 0}, xi = (d4){0, 0, 0, 0};
-        const double* wr = WtR + jb * TL_TILE;
-        const double* wi = WtI + jb * TL_TILE;
+        __syncthreads();  // (A) diagonal tile published
+        STAMP(6);
+        diag_coop(Dc, Zc, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, tid);  // ends with a barrier
+        STAMP(10);
+        // ---- panel tiles (P > jb, Q == jb): X = T W^H, published as Pan[P][k][row]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int o = (4 * ks + lq) * TL_LD + lcol;
-          const double aR = tr[o], aI = ti[o], bR = wr[o], bI = wi[o];
-          xr = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, xr, 0, 0, 0);
-          xr = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bI, xr, 0, 0, 0);
-          xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, xi, 0, 0, 0);
-          xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bR, xi, 0, 0, 0);
-        }
-        accR[sl] = xr; accI[sl] = xi;  // the finished L tile stays here for the back substitution
-        double* pr = PanR + tP[sl] * TL_TILE;
-        double* pi = PanI + tP[sl] * TL_TILE;
+        for (int sl = 0; sl < NS; ++sl) {
+          if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
+          double* tr = TmpR + wave * TL_TILE;
+          double* ti = TmpI + wave * TL_TILE;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[lcol * TL_LD + lq + 4 * r] = xr[r];
-          pi[lcol * TL_LD + lq + 4 * r] = xi[r];
-        }
-      }
-      __syncthreads();
-      // ---- trailing tiles (P >= Q > jb): T -= L[P][jb] L[Q][jb]^H
-#pragma unroll
-      for (int sl = 0; sl < TL_NS; ++sl) {
-        if (!live[sl] || tQ[sl] <= jb) continue;
-        const double* ar = PanR + tP[sl] * TL_TILE;
-        const double* ai = PanI + tP[sl] * TL_TILE;
-        const double* br = PanR + tQ[sl] * TL_TILE;
-        const double* bi = PanI + tQ[sl] * TL_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int o = (4 * ks + lq) * TL_LD + lcol;
-          const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];
-          accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aR, lR, accR[sl], 0, 0, 0);
-          accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lI, accR[sl], 0, 0, 0);
-          accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lI, accI[sl], 0, 0, 0);
-          accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lR, accI[sl], 0, 0, 0);
-        }
-      }
-      // (the barrier after the next diagonal step orders these LDS reads before the next panel's writes)
-    }
-    __syncthreads();
-
-    // ================= back substitution  L^H x = y,  y = conj(row `is` of the last tile row) =================
-#pragma unroll
-    for (int sl = 0; sl < TL_NS; ++sl) {
-      if (!live[sl] || tP[sl] != nt - 1 || tQ[sl] == nt - 1) continue;
-      if (lq == (is & 3)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r == (is >> 2)) {
-            zv[2 * (16 * tQ[sl] + lcol)] = accR[sl][r];
-            zv[2 * (16 * tQ[sl] + lcol) + 1] = -accI[sl][r];
+          for (int r = 0; r < 4; ++r) {  // T[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
+            tr[lcol * TL_LD + lq + 4 * r] = accR[sl][r];
+            ti[lcol * TL_LD + lq + 4 * r] = accI[sl][r];
           }
-      }
-    }
-    if (tid < 16) {
-      const bool ok = tid < is;
-      zv[2 * (16 * (nt - 1) + tid)] = ok ? LdR[is * TL_LD + tid] : 0.0;
-      zv[2 * (16 * (nt - 1) + tid) + 1] = ok ? -LdI[is * TL_LD + tid] : 0.0;
-    }
-    for (int q = tid; q < 4 * Kc; q += nt_thr) xs[q] = 0.0;
-    __syncthreads();
-    for (int P = nt - 1; P >= 0; --P) {
-      if (tid < 16) {  // x_P = W_PP^H z_P : row tid of (W^H)
-        const double* wr = WtR + P * TL_TILE + tid * TL_LD;
-        const double* wi = WtI + P * TL_TILE + tid * TL_LD;
-        double xr = 0, xi = 0;
-        for (int k = tid; k < 16; ++k) {
-          const double zr = zv[2 * (16 * P + k)], zi = zv[2 * (16 * P + k) + 1];
-          xr += wr[k] * zr - wi[k] * zi;
-          xi += wr[k] * zi + wi[k] * zr;
-        }
-        xv[2 * tid] = xr; xv[2 * tid + 1] = xi;
-        int I, alpha;
-        block_of(P, nt, I, alpha);
-        const int col = 16 * I + tid;
-        if (col < Kc) { xs[2 * (alpha * Kc + col)] = xr; xs[2 * (alpha * Kc + col) + 1] = xi; }
-      }
-      __syncthreads();
+          __builtin_amdgcn_wave_barrier();
+          d4 xr = (d4){0, 0, 0, 0}, xi = (d4){0, 0, 0, 0};
+          const double* wr = WtR + jb * TL_TILE;
+          const double* wi = WtI + jb * TL_TILE;
 #pragma unroll
-      for (int sl = 0; sl < TL_NS; ++sl) {
-        if (!live[sl] || tP[sl] != P || tQ[sl] == P) continue;
-        double sr = 0, si = 0;  // sum_i conj(L[i][j]) x[i] over this lane's rows i = lq + 4r
+          for (int ks = 0; ks < 4; ++ks) {
+            const int o = (4 * ks + lq) * TL_LD + lcol;
+            const double aR = tr[o], aI = ti[o], bR = wr[o], bI = wi[o];
+            xr = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, xr, 0, 0, 0);
+            xr = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bI, xr, 0, 0, 0);
+            xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, xi, 0, 0, 0);
+            xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bR, xi, 0, 0, 0);
+          }
+          accR[sl] = xr; accI[sl] = xi;  // the finished L tile stays here for the back substitution
+          double* pr = PanR + tP[sl] * TL_TILE;
+          double* pi = PanI + tP[sl] * TL_TILE;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double xr = xv[2 * (lq + 4 * r)], xi = xv[2 * (lq + 4 * r) + 1];
-          const double lr = accR[sl][r], li = accI[sl][r];
-          sr += lr * xr + li * xi;
-          si += lr * xi - li * xr;
+          for (int r = 0; r < 4; ++r) {
+            pr[lcol * TL_LD + lq + 4 * r] = xr[r];
+            pi[lcol * TL_LD + lq + 4 * r] = xi[r];
+          }
         }
-        sr += __shfl_xor(sr, 16); si += __shfl_xor(si, 16);
-        sr += __shfl_xor(sr, 32); si += __shfl_xor(si, 32);
-        if (lq == 0) {
-          zv[2 * (16 * tQ[sl] + lcol)] -= sr;
-          zv[2 * (16 * tQ[sl] + lcol) + 1] -= si;
+        __syncthreads();  // (C)
+        STAMP(7);
+        // ---- trailing tiles (P >= Q > jb): T -= L[P][jb] L[Q][jb]^H
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          if (!live[sl] || tQ[sl] <= jb) continue;
+          const double* ar = PanR + tP[sl] * TL_TILE;
+          const double* ai = PanI + tP[sl] * TL_TILE;
+          const double* br = PanR + tQ[sl] * TL_TILE;
+          const double* bi = PanI + tQ[sl] * TL_TILE;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int o = (4 * ks + lq) * TL_LD + lcol;
+            const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aR, lR, accR[sl], 0, 0, 0);
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lI, accR[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lI, accI[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lR, accI[sl], 0, 0, 0);
+          }
+        }
+        STAMP(8);
+        // (barrier A of the next panel orders these LDS reads before the next panel's writes)
+      }
+      __syncthreads();  // end of factorisation
+      STAMP(3);
+
+      // ============ back substitution  L^H x = y,  y = conj(row `is` of the last tile row) ============
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        if (!live[sl] || tP[sl] != nt - 1 || tQ[sl] == nt - 1) continue;
+        if (lq == (is & 3)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r == (is >> 2)) {
+              zv[2 * (16 * tQ[sl] + lcol)] = accR[sl][r];
+              zv[2 * (16 * tQ[sl] + lcol) + 1] = -accI[sl][r];
+            }
         }
       }
-      __syncthreads();
+      if (tid < 16) {
+        const bool ok = tid < is;
+        zv[2 * (16 * (nt - 1) + tid)] = ok ? LdR[is * TL_LD + tid] : 0.0;
+        zv[2 * (16 * (nt - 1) + tid) + 1] = ok ? -LdI[is * TL_LD + tid] : 0.0;
+      }
+      for (int q = tid; q < 4 * Kc; q += nt_thr) xs[q] = 0.0;
+      __syncthreads();  // y gathered
+      for (int P = nt - 1; P >= 0; --P) {
+        if (tid < 16) {  // x_P = W_PP^H z_P : row tid of (W^H)
+          const double* wr = WtR + P * TL_TILE + tid * TL_LD;
+          const double* wi = WtI + P * TL_TILE + tid * TL_LD;
+          double xr = 0, xi = 0;
+          for (int k = tid; k < 16; ++k) {
+            const double zr = zv[2 * (16 * P + k)], zi = zv[2 * (16 * P + k) + 1];
+            xr += wr[k] * zr - wi[k] * zi;
+            xi += wr[k] * zi + wi[k] * zr;
+          }
+          xv[2 * tid] = xr; xv[2 * tid + 1] = xi;
+          int I, alpha;
+          block_of(P, nt, I, alpha);
+          const int col = 16 * I + tid;
+          if (col < Kc) { xs[2 * (alpha * Kc + col)] = xr; xs[2 * (alpha * Kc + col) + 1] = xi; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          if (!live[sl] || tP[sl] != P || tQ[sl] == P) continue;
+          double sr = 0, si = 0;  // sum_i conj(L[i][j]) x[i] over this lane's rows i = lq + 4r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double xr = xv[2 * (lq + 4 * r)], xi = xv[2 * (lq + 4 * r) + 1];
+            const double lr = accR[sl][r], li = accI[sl][r];
+            sr += lr * xr + li * xi;
+            si += lr * xi - li * xr;
+          }
+          sr += __shfl_xor(sr, 16); si += __shfl_xor(si, 16);
+          sr += __shfl_xor(sr, 32); si += __shfl_xor(si, 32);
+          if (lq == 0) {
+            zv[2 * (16 * tQ[sl] + lcol)] -= sr;
+            zv[2 * (16 * tQ[sl] + lcol) + 1] -= si;
+          }
+        }
+        __syncthreads();
+      }
+      STAMP(4);
     }
 
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
+    STAMP(5);
   }
 }
 
-size_t ls_tile_scratch_stride(int nmax, int Nmax) { return ((size_t)2 * (Nmax + 1) * nmax + 15) & ~(size_t)15; }
+// the tile variant needs its LDS budget (which grows with Kmax through the solution vector) to fit
+bool ls_tile_applicable(int Kcmax, int Nmax) {
+  const size_t usize_c = (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_WAVES * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
+  return Nmax <= 64 * CI_NCH && (usize_c + 4 * (size_t)Kcmax + 16) * sizeof(double) <= 160 * 1024;
+}
 
-// A.scratch / A.scratch_stride / A.work_counter are set by the caller (eaqhm_ls_batch)
+size_t ls_tile_scratch_stride(int nmax, int Nmax) {
+  const size_t Npad = (size_t)((Nmax + 63) >> 6) << 6;
+  return (2 * Npad * nmax + 15) & ~(size_t)15;
+}
+
+// A.scratch / A.scratch_stride / A.work_counter (5 ints) / A.debug are set by the caller (eaqhm_ls_batch)
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
-  const int nmax = A.nmax, Kcmax = A.Kcmax;
+  const int Kcmax = A.Kcmax;
   const int ldx_max = 16 * TL_NBMAX + 16;
   const int TS = 32;
-  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS;
-  const size_t usize_c = (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_WAVES * TL_TILE + 2 * TL_TILE + 2 * 16 * TL_NTMAX + 32;
-  const size_t lds_doubles = (usize_c > usize_g ? usize_c : usize_g) + 2 * (size_t)nmax + 4 * (size_t)Kcmax + 16;
-  const size_t lds_bytes = lds_doubles * sizeof(double);
+  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS + (size_t)CI_STRIDE * 48 + 48 * CI_NCH;
+  const size_t usize_c = (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_WAVES * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
+  if (usize_g > usize_c) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: internal LDS layout error");
+  const size_t lds_bytes = (usize_c + 4 * (size_t)Kcmax + 16) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-  hipLaunchKernelGGL(eaqhm_ls_tile_kernel, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max);
+  // one instantiation per register budget; each pulls every frame from its own queue and keeps its sizes
+  int* counters = A.work_counter;
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  A.work_counter = counters + 2;  // nb = 5: 55 tiles over 8 waves -> 7 slots
+  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<7>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 5, 5);
+  A.work_counter = counters + 3;  // nb <= 4: 36 tiles -> 5 slots
+  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<5>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 1, 4);
+  if (Kcmax + 1 > 16 * 5) {
+    A.work_counter = counters + 4;  // nb = 6: 78 tiles -> 10 slots
+    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<10>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 6, 6);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

@@ -20,6 +20,7 @@ SYMBOLS = (
     ("eaqhm_sync", C.c_int, [_P]),
     ("eaqhm_last_error", C.c_char_p, [_P]),
     ("eaqhm_set_option", C.c_int, [_P, _I32, _I32]),
+    ("eaqhm_debug_read", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("eaqhm_device_info", C.c_int, [_P, C.POINTER(_I32)]),
     ("eaqhm_frame_prep", C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
     ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -118,6 +119,11 @@ class Context:
 
     def set_option(self, key, value):
         self._ck(self.lib.eaqhm_set_option(self.h, key, value))
+
+    def debug_read(self):
+        out = (C.c_uint64 * 16)()
+        self._ck(self.lib.eaqhm_debug_read(self.h, out))
+        return [int(v) for v in out]
 
     def sync(self):
         self._ck(self.lib.eaqhm_sync(self.h))

@@ -54,7 +54,11 @@ const char* eaqhm_last_error(eaqhm_ctx* ctx);
  *                         3 = Gramian and tile Cholesky on chip for frames of <= 6 column blocks, 2 for the rest
  *                             (default) */
 #define EAQHM_OPT_LS_VARIANT 1
+#define EAQHM_OPT_DEBUG_KEEP 2   /* 1: accumulate the in-kernel phase stamps across launches */
 int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value);
+/* diagnostics: shader-clock cycles per phase of the LS tile kernel summed over frames (thread 0 of each
+ * workgroup): {setup, basis build, contraction, factorisation total..., see csrc/eaqhm_ls_tile.hip STAMP} */
+int eaqhm_debug_read(eaqhm_ctx* ctx, uint64_t h_out[16]);
 /* library / device facts: fills {n_cu, lds_bytes, clock_khz, abi_version} */
 int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
 
