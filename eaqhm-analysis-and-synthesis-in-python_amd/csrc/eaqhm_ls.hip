@@ -318,8 +318,8 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
       B.scratch_stride = st_t; B.work_counter = counters;
       rc = launch_ls_tile(ctx, B, grid);
       if (rc) return rc;
-      min_nb = 7;
-      if (Kcmax + 1 <= 16 * 6) return EAQHM_OK;   // no frame can be larger: skip the second launch
+      min_nb = 1;
+      if ((2 * Kcmax + 1 + 15) / 16 <= 13) return EAQHM_OK;   // no frame can be larger: skip the second launch
     }
     B.scratch_stride = st_m; B.work_counter = counters + 1;
     return launch_ls_mfma(ctx, B, grid, min_nb);

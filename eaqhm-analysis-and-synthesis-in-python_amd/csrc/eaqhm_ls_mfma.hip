@@ -81,7 +81,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
     const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc, ldl = M + 1;
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
-    if (nb < min_nb) continue;                   // small frames were done by eaqhm_ls_tile_kernel
+    if (min_nb > 0 && (2 * Kc + 1 + 15) / 16 <= 13) continue;  // done by eaqhm_ls_tile_kernel (<= 13 tile rows)
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
     const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
     const int npass = (units + MF_WAVES * MF_NSLOT - 1) / (MF_WAVES * MF_NSLOT);

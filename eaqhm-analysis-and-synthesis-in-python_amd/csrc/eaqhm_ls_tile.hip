@@ -5,14 +5,12 @@
 // system tiles in their registers, and 1 specialist wave that factorises the diagonal tiles (its register
 // file is free of accumulators, so the serial 16-column chain runs without spills).
 //
-// Unknown ordering.  The basis columns are cut into nb blocks of 16 ([negative | DC | positive | signal | 0-pad]).
-// Unknowns are ordered block by block, amplitudes (alpha=0) then slopes (alpha=1) of each block, except that
-// the amplitude part of the LAST block comes last.  The signal window is the last real column of that block,
-// so its row of the Hermitian system is the last real row: factorising the matrix WITH that row/column leaves
-// conj(L^-1 rhs) in it — the forward substitution costs nothing.  System tile (P,Q) = G_{alpha_P+alpha_Q}[I_P][I_Q]
-// with G_p = X^H diag(w^2 n^p) X: every 16x16 complex system tile is one MFMA accumulation over time, owned by
-// one compute wave (tile x = P(P+1)/2+Q -> wave x%7, slot x/7) from the first sample to the last
-// back-substitution step.
+// Stacked basis.  With Y[t] = w_t * [ E2(t) | n_t E2(t) | s_t ]  (2Kc+1 columns; E2 = [negative | DC | positive]
+// columns of functions.py:516-519, w the analysis window, n_t = t - mid) the normal equations of
+// functions.py:521-530 are the leading 2Kc x 2Kc block of  Y^H Y  and the right-hand side is its last column.
+// Factorising  Y^H Y  WITH that last row/column leaves conj(L^-1 rhs) in the last row: the forward substitution
+// costs nothing.  Every 16x16 complex tile of Y^H Y is one MFMA accumulation over time, owned by one wave
+// (tile x = P(P+1)/2+Q -> wave x%8, slot x/8) from the first sample to the last back-substitution step.
 //
 //   A1     one wave per (slot, 64-sample chunk): coalesced track windows, gaps found with ballots and bridged,
 //          wave scan of fm                                                                  -> global scratch
@@ -25,7 +23,7 @@
 //   C'     back substitution from the L tiles still sitting in the owners' registers; z, x vectors in LDS
 //   D      frequency mismatch, acceptance, record row (eaqhm_ls_common.h)
 //
-// Frames with more than 6 column blocks (Kc > 95) do not fit the register budget and are left to
+// Frames with more than 13 tile rows (Kc > 103) do not fit the register budget and are left to
 // eaqhm_ls_mfma_kernel (same Gramian, factorisation through scratch memory).
 #include "eaqhm_ls_common.h"
 
@@ -36,8 +34,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define TL_THREADS 512
 #define TL_WAVES 8
 #define TL_CW 8         // all waves own tiles
-#define TL_NBMAX 6
-#define TL_NTMAX 12
+#define TL_NTMAX 13
 #define TL_LD 17        // tile row stride in LDS (doubles): conflict-free transposing stores
 #define TL_TILE (16 * TL_LD)
 #define CI_STRIDE 20    // per-slot info: 16 chunk carries, qmid, 1/(am_mid+eps), rho.re, rho.im
@@ -50,12 +47,6 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   while (P * (P + 1) / 2 > x) --P;
   Q = x - P * (P + 1) / 2;
 }
-// position in the unknown ordering -> (column block, alpha)
-__device__ inline void block_of(int P, int nt, int& I, int& alpha) {
-  if (P < nt - 2) { I = P >> 1; alpha = P & 1; }
-  else { I = (nt >> 1) - 1; alpha = (P == nt - 2) ? 1 : 0; }
-}
-
 // ---- Phase A1 -----------------------------------------------------------------------------------------------
 //   Qloc[j][t]  scan of fm inside its 64-sample chunk         (global scratch, row stride Npad)
 //   Af[j][t]    gap-filled am                                  (global scratch)
@@ -205,17 +196,14 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
   double* U = lds;
   double* Xre = U;
   double* Xim = Xre + (size_t)TS * ldx_max;
-  double* Wp = Xim + (size_t)TS * ldx_max;           // 3*TS  weights w^2 n^p per chunk row
-  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS;
+  const size_t usize_g = (size_t)2 * TS * ldx_max;
   double* ci = U + usize_g;                          // [48][CI_STRIDE]
   unsigned long long* masks = (unsigned long long*)(ci + (size_t)CI_STRIDE * 48);  // [48][16]
   double* PanR = U;                                  // [NT][TILE]  published panel tiles, [k][row]
   double* PanI = PanR + TL_NTMAX * TL_TILE;
   double* WtR = PanI + TL_NTMAX * TL_TILE;           // [NT][TILE]  (W^H)[k][j] of every diagonal tile
   double* WtI = WtR + TL_NTMAX * TL_TILE;
-  double* TmpR = WtI + TL_NTMAX * TL_TILE;           // [8][TILE]   per-wave transposition buffer
-  double* TmpI = TmpR + TL_WAVES * TL_TILE;
-  double* LdR = TmpI + TL_WAVES * TL_TILE;           // [TILE]      last diagonal factor, [row][col]
+  double* LdR = WtI + TL_NTMAX * TL_TILE;            // [TILE]      last diagonal factor, [row][col]
   double* LdI = LdR + TL_TILE;
   double* Dc = LdI + TL_TILE;                        // [512]       diagonal tile being factorised (complex, row-major)
   double* Zc = Dc + 512;                             // [512]       its inverse in the making
@@ -225,6 +213,7 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
   double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
   double* sh = xs + 4 * A.Kcmax;                     // 16
   int* shi = (int*)(sh + 12);
+  double* win = sh + 16;                             // [64*CI_NCH] analysis window of the frame
 
   const int Npad = ((A.Nmax + 63) >> 6) << 6;
   double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
@@ -250,15 +239,14 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
     __syncthreads();
     if (f >= A.n_frames) break;
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
-    const int Kc = 2 * n + 1, C1 = Kc + 1;
-    const int nb = (C1 + 15) >> 4;
-    if (nb < nb_lo || nb > nb_hi) continue;  // another instantiation (or eaqhm_ls_mfma_kernel) owns this frame
+    const int Kc = 2 * n + 1, Ms = 2 * Kc + 1;   // stacked columns incl. the signal
+    const int nt = (Ms + 15) >> 4;
+    if (nt < nb_lo || nt > nb_hi) continue;  // another instantiation (or eaqhm_ls_mfma_kernel) owns this frame
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
     const int N = 2 * wl + 1, mid = wl;
-    const int C1p = nb << 4;
-    const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
-    const int nt = 2 * nb, ntiles = nt * (nt + 1) / 2;
-    const int is = Kc - 16 * (nb - 1);  // position of the signal column inside the last block (1..15)
+    const int ldx = (nt << 4) + ((nt & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
+    const int ntiles = nt * (nt + 1) / 2;
+    const int is = 2 * Kc - 16 * (nt - 1);  // position of the signal column inside the last tile row (2,6,10,14)
     const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
@@ -266,6 +254,7 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
     for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
+    for (int t = tid; t < N; t += nt_thr) win[t] = window_value(A.mode == 0, t, N);
     __syncthreads();
     if (A.mode == 1) fill_columns_par(A, Qs, Rs, Npad, ci, masks, mycols, n, N, mid, c, wl, seeds, lane, wave);
     STAMP(0);
@@ -297,7 +286,10 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
         double su = 0, cu = 1, sv, cv;
         double* xr = Xre + (2 * el) * ldx;
         double* xi = Xim + (2 * el) * ldx;
-        const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);
+        const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);               // amplitude columns
+        const int spos = XCOL(Kc + n + 1 + j, el), sneg = XCOL(Kc + j, el);     // slope columns (n_t times)
+        const double wv = win[v], nv = (double)(v - mid);
+        double pur = 0, pui = 0, nur = 0, nui = 0, pvr, pvi, nvr, nvi;  // positive / negative column values
         if (A.mode == 1) {
           const double* cj = ci + j * CI_STRIDE;
           const double qmid = cj[16], ainv = cj[17], pr = cj[18], pi = cj[19];
@@ -311,57 +303,62 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
           // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
           if (u >= 0) {
             const double ru = (eps + af[u]) * ainv, rv1 = (eps + af[v + 1]) * ainv;
-            xr[cpos] = ru * cu;                    xi[cpos] = ru * su;
-            xr[cneg] = rv1 * (cv * pr - sv * pi);  xi[cneg] = rv1 * (cv * pi + sv * pr);
+            pur = ru * cu;                    pui = ru * su;
+            nur = rv1 * (cv * pr - sv * pi);  nui = rv1 * (cv * pi + sv * pr);
           }
           const double rv = (eps + af[v]) * ainv, ru1 = (eps + af[u + 1]) * ainv;
-          xr += ldx; xi += ldx;
-          xr[cpos] = rv * cv;                      xi[cpos] = rv * sv;
-          xr[cneg] = ru1 * (cu * pr - su * pi);    xi[cneg] = ru1 * (cu * pi + su * pr);
+          pvr = rv * cv;                      pvi = rv * sv;
+          nvr = ru1 * (cu * pr - su * pi);    nvi = ru1 * (cu * pi + su * pr);
         } else {  // adaptation 0: exp(j 2 pi k f0 n / fs), negative column = conjugate (functions.py:453-454)
           const double fk = (double)(j + 1) * f0;
           if (u >= 0) {
             sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
-            xr[cpos] = cu; xi[cpos] = su; xr[cneg] = cu; xi[cneg] = -su;
+            pur = cu; pui = su; nur = cu; nui = -su;
           }
           sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
-          xr += ldx; xi += ldx;
-          xr[cpos] = cv; xi[cpos] = sv; xr[cneg] = cv; xi[cneg] = -sv;
+          pvr = cv; pvi = sv; nvr = cv; nvi = -sv;
         }
+        if (u >= 0) {
+          const double wu = win[u], nu = (double)(u - mid);
+          pur *= wu; pui *= wu; nur *= wu; nui *= wu;
+          xr[cpos] = pur;      xi[cpos] = pui;      xr[cneg] = nur;      xi[cneg] = nui;
+          xr[spos] = nu * pur; xi[spos] = nu * pui; xr[sneg] = nu * nur; xi[sneg] = nu * nui;
+        }
+        pvr *= wv; pvi *= wv; nvr *= wv; nvi *= wv;
+        xr += ldx; xi += ldx;
+        xr[cpos] = pvr;      xi[cpos] = pvi;      xr[cneg] = nvr;      xi[cneg] = nvi;
+        xr[spos] = nv * pvr; xi[spos] = nv * pvi; xr[sneg] = nv * nvr; xi[sneg] = nv * nvi;
       }
 #pragma clang loop unroll(disable)
       for (int row = tid; row < TS; row += nt_thr) {
         const int e = e0 + (row >> 1);
         const int t = (row & 1) ? (N - 1 - e) : (e - 1);
-        double w0 = 0.0, sval = 0.0;
-        if (e < npairs && t >= 0) {
-          double w = window_value(A.mode == 0, t, N);
-          w0 = w * w;
-          sval = A.s[(size_t)(c - wl) + t];
-        }
+        const bool ok = (e < npairs) && (t >= 0);
+        const double w = ok ? win[t] : 0.0;
+        const double sval = ok ? A.s[(size_t)(c - wl) + t] : 0.0;
         const double nn = (double)(t - mid);
-        Wp[row] = w0; Wp[TS + row] = w0 * nn; Wp[2 * TS + row] = w0 * nn * nn;
         const int el = row >> 1;
-        Xre[row * ldx + XCOL(n, el)] = 1.0;    Xim[row * ldx + XCOL(n, el)] = 0.0;   // DC column
-        Xre[row * ldx + XCOL(Kc, el)] = sval;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
+        double* xr = Xre + row * ldx;
+        double* xi = Xim + row * ldx;
+        xr[XCOL(n, el)] = w;               xi[XCOL(n, el)] = 0.0;            // DC column
+        xr[XCOL(Kc + n, el)] = w * nn;     xi[XCOL(Kc + n, el)] = 0.0;       // its slope copy
+        xr[XCOL(2 * Kc, el)] = w * sval;   xi[XCOL(2 * Kc, el)] = 0.0;       // signal column
+        if (!ok) {  // rows beyond the window (tail of the last chunk, the virtual sample u = -1): all zero
+          for (int q = 0; q < Ms; ++q) { xr[XCOL(q, el)] = 0.0; xi[XCOL(q, el)] = 0.0; }
+        }
       }
       __syncthreads();
       STAMP(1);
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
         if (!live[sl]) continue;
-        int Ia, aa, Ib, ab;
-        block_of(tP[sl], nt, Ia, aa);
-        block_of(tQ[sl], nt, Ib, ab);
-        const double* wrow = Wp + (aa + ab) * TS + lq;
+        const int ca = 16 * tP[sl], cb = 16 * tQ[sl];
 #pragma clang loop unroll(disable)
         for (int ks = 0; ks < TS / 4; ++ks) {
           const int row = 4 * ks + lq;
           const int sw = (lcol + (row >> 1)) & 15;
-          const int oa = row * ldx + 16 * Ia + sw, ob = row * ldx + 16 * Ib + sw;
-          const double aR = Xre[oa], aI = Xim[oa];
-          const double w = wrow[4 * ks];
-          const double bR = w * Xre[ob], bI = w * Xim[ob];
+          const int oa = row * ldx + ca + sw, ob = row * ldx + cb + sw;
+          const double aR = Xre[oa], aI = Xim[oa], bR = Xre[ob], bI = Xim[ob];
           accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
           accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
           accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
@@ -374,21 +371,16 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
 
     {
       // ================= compute waves =================
-      // ---- neutralise dummy unknowns: in the last column block the positions >= is of the slope part (the
-      // signal column's slope + padding) and the positions > is of the amplitude part (padding) get an identity
-      // row/column; position `is` of the amplitude part is the RHS row/column and stays.
+      // ---- padding positions of the last tile row/column (beyond the signal) get an identity row/column
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
-        if (!live[sl]) continue;
-        const int P = tP[sl], Q = tQ[sl];
-        if (P < nt - 2) continue;
+        if (!live[sl] || tP[sl] != nt - 1) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = lq + 4 * r, col = lcol;
-          const bool drow = (P == nt - 2) ? (row >= is) : (row > is);
-          const bool dcol = (Q == nt - 2) ? (col >= is) : ((Q == nt - 1) ? (col > is) : false);
-          if (drow || dcol) {
-            accR[sl][r] = (P == Q && row == col) ? 1.0 : 0.0;
+          const bool pad = (row > is) || (tQ[sl] == nt - 1 && col > is);
+          if (pad) {
+            accR[sl][r] = (tQ[sl] == nt - 1 && row == col) ? 1.0 : 0.0;
             accI[sl][r] = 0.0;
           }
         }
@@ -415,8 +407,8 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
           if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
-          double* tr = TmpR + wave * TL_TILE;
-          double* ti = TmpI + wave * TL_TILE;
+          double* tr = PanR + tP[sl] * TL_TILE;   // the tile's own panel slot doubles as transposition buffer
+          double* ti = PanI + tP[sl] * TL_TILE;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // T[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
             tr[lcol * TL_LD + lq + 4 * r] = accR[sl][r];
@@ -436,12 +428,11 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
             xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bR, xi, 0, 0, 0);
           }
           accR[sl] = xr; accI[sl] = xi;  // the finished L tile stays here for the back substitution
-          double* pr = PanR + tP[sl] * TL_TILE;
-          double* pi = PanI + tP[sl] * TL_TILE;
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pr[lcol * TL_LD + lq + 4 * r] = xr[r];
-            pi[lcol * TL_LD + lq + 4 * r] = xi[r];
+            tr[lcol * TL_LD + lq + 4 * r] = xr[r];
+            ti[lcol * TL_LD + lq + 4 * r] = xi[r];
           }
         }
         __syncthreads();  // (C)
@@ -501,10 +492,8 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
             xi += wr[k] * zi + wi[k] * zr;
           }
           xv[2 * tid] = xr; xv[2 * tid + 1] = xi;
-          int I, alpha;
-          block_of(P, nt, I, alpha);
-          const int col = 16 * I + tid;
-          if (col < Kc) { xs[2 * (alpha * Kc + col)] = xr; xs[2 * (alpha * Kc + col) + 1] = xi; }
+          const int q = 16 * P + tid;   // natural order: amplitudes then slopes
+          if (q < 2 * Kc) { xs[2 * q] = xr; xs[2 * q + 1] = xi; }
         }
         __syncthreads();
 #pragma unroll
@@ -535,10 +524,18 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
   }
 }
 
+static size_t tl_usize_c() {
+  return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
+}
+static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 48 + 48 * CI_NCH; }
+static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
+  const size_t c = tl_usize_c(), g = tl_usize_g(TS, ldx_max);
+  return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 64 * CI_NCH;
+}
+
 // the tile variant needs its LDS budget (which grows with Kmax through the solution vector) to fit
 bool ls_tile_applicable(int Kcmax, int Nmax) {
-  const size_t usize_c = (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_WAVES * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
-  return Nmax <= 64 * CI_NCH && (usize_c + 4 * (size_t)Kcmax + 16) * sizeof(double) <= 160 * 1024;
+  return Nmax <= 64 * CI_NCH && tl_lds_doubles(Kcmax, 32, 16 * TL_NTMAX + 16) * sizeof(double) <= 160 * 1024;
 }
 
 size_t ls_tile_scratch_stride(int nmax, int Nmax) {
@@ -546,28 +543,32 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
   return (2 * Npad * nmax + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.work_counter (5 ints) / A.debug are set by the caller (eaqhm_ls_batch)
+// A.scratch / A.scratch_stride / A.work_counter (6 ints) / A.debug are set by the caller (eaqhm_ls_batch).
+// Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int Kcmax = A.Kcmax;
-  const int ldx_max = 16 * TL_NBMAX + 16;
+  const int ldx_max = 16 * TL_NTMAX + 16;
   const int TS = 32;
-  const size_t usize_g = (size_t)2 * TS * ldx_max + 3 * TS + (size_t)CI_STRIDE * 48 + 48 * CI_NCH;
-  const size_t usize_c = (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_WAVES * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
-  if (usize_g > usize_c) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: internal LDS layout error");
-  const size_t lds_bytes = (usize_c + 4 * (size_t)Kcmax + 16) * sizeof(double);
+  const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+  const int nt_possible = (2 * Kcmax + 1 + 15) / 16;
   // one instantiation per register budget; each pulls every frame from its own queue and keeps its sizes
   int* counters = A.work_counter;
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  A.work_counter = counters + 2;  // nb = 5: 55 tiles over 8 waves -> 7 slots
-  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<7>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 5, 5);
-  A.work_counter = counters + 3;  // nb <= 4: 36 tiles -> 5 slots
-  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<5>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 1, 4);
-  if (Kcmax + 1 > 16 * 5) {
-    A.work_counter = counters + 4;  // nb = 6: 78 tiles -> 10 slots
-    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<10>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 6, 6);
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  A.work_counter = counters + 2;  // 9-10 tile rows (Kc 64..79): 45 / 55 tiles -> 7 slots per wave
+  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<7>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 9, 10);
+  A.work_counter = counters + 3;  // <= 8 tile rows (Kc <= 63): <= 36 tiles -> 5 slots
+  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<5>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 1, 8);
+  if (nt_possible >= 11) {
+    A.work_counter = counters + 4;  // 11 tile rows (Kc 80..87): 66 tiles -> 9 slots
+    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<9>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 11, 11);
+  }
+  if (nt_possible >= 12) {
+    A.work_counter = counters + 5;  // 12-13 tile rows (Kc 88..103): 78 / 91 tiles -> 12 slots
+    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<12>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 12, 13);
   }
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
