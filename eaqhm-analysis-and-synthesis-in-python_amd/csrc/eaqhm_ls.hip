@@ -315,7 +315,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
     B.scratch = (double*)ctx->scratch;
     int min_nb = 0;
     if (ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax)) {   // small frames: everything in registers/LDS; the rest falls through
-      B.scratch_stride = st_t; B.work_counter = counters;
+      B.scratch_stride = st_t; B.work_counter = counters + 2;
       rc = launch_ls_tile(ctx, B, grid);
       if (rc) return rc;
       min_nb = 1;

@@ -186,8 +186,7 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
 }
 
 template <int NS>
-__global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max, int nb_lo, int nb_hi) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, int ldx_max, double* lds, int f) {
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,7 +211,6 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
   const size_t usize_c = (size_t)(xv + 32 - U);
   double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
   double* sh = xs + 4 * A.Kcmax;                     // 16
-  int* shi = (int*)(sh + 12);
   double* win = sh + 16;                             // [64*CI_NCH] analysis window of the frame
 
   const int Npad = ((A.Nmax + 63) >> 6) << 6;
@@ -232,16 +230,10 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
     }                                                               \
   } while (0)
 
-  for (;;) {
-    if (tid == 0) shi[0] = atomicAdd(A.work_counter, 1);
-    __syncthreads();
-    const int f = shi[0];
-    __syncthreads();
-    if (f >= A.n_frames) break;
+  {
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
     const int Kc = 2 * n + 1, Ms = 2 * Kc + 1;   // stacked columns incl. the signal
     const int nt = (Ms + 15) >> 4;
-    if (nt < nb_lo || nt > nb_hi) continue;  // another instantiation (or eaqhm_ls_mfma_kernel) owns this frame
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
     const int N = 2 * wl + 1, mid = wl;
     const int ldx = (nt << 4) + ((nt & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
@@ -524,6 +516,26 @@ __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int
   }
 }
 
+// One launch for every frame size: the frame queue hands out frames, the register budget (tiles per wave) is
+// chosen per frame.  Frames with more than TL_NTMAX tile rows are skipped (caller's fallback kernel).
+extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int next_frame;
+  for (;;) {
+    if (threadIdx.x == 0) next_frame = atomicAdd(A.work_counter, 1);
+    __syncthreads();
+    const int f = next_frame;
+    __syncthreads();
+    if (f >= A.n_frames) break;
+    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
+    const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
+    if (nt <= 8) tile_frame<5>(A, TS, ldx_max, lds, f);         // <= 36 tiles
+    else if (nt <= 10) tile_frame<7>(A, TS, ldx_max, lds, f);   // 45 / 55 tiles
+    else if (nt == 11) tile_frame<9>(A, TS, ldx_max, lds, f);   // 66 tiles
+    else if (nt <= TL_NTMAX) tile_frame<12>(A, TS, ldx_max, lds, f);  // 78 / 91 tiles
+  }
+}
+
 static size_t tl_usize_c() {
   return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
 }
@@ -551,25 +563,8 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int TS = 32;
   const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
-  const int nt_possible = (2 * Kcmax + 1 + 15) / 16;
-  // one instantiation per register budget; each pulls every frame from its own queue and keeps its sizes
-  int* counters = A.work_counter;
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  A.work_counter = counters + 2;  // 9-10 tile rows (Kc 64..79): 45 / 55 tiles -> 7 slots per wave
-  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<7>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 9, 10);
-  A.work_counter = counters + 3;  // <= 8 tile rows (Kc <= 63): <= 36 tiles -> 5 slots
-  hipLaunchKernelGGL(eaqhm_ls_tile_kernel<5>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 1, 8);
-  if (nt_possible >= 11) {
-    A.work_counter = counters + 4;  // 11 tile rows (Kc 80..87): 66 tiles -> 9 slots
-    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<9>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 11, 11);
-  }
-  if (nt_possible >= 12) {
-    A.work_counter = counters + 5;  // 12-13 tile rows (Kc 88..103): 78 / 91 tiles -> 12 slots
-    hipLaunchKernelGGL(eaqhm_ls_tile_kernel<12>, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, 12, 13);
-  }
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(eaqhm_ls_tile_kernel, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }
