@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 (vector = matrix) spec: half the 157.3 TF FP32 vector peak
-                          # of MI355X_MICROARCH.md's chip table; measured here: mfma 44, v_fma_f64 63 TF/s
+                          # of MI355X_MICROARCH.md's chip table; measured here: mfma_f64 48, v_fma_f64 63 TF/s
 
 
 def ls_flops(N, Kc):
@@ -156,8 +156,16 @@ def main():
     flops_step = sum(flops_per_launch)
     ls_total_s = sum(ls_ms) / 1e3
     achieved = flops_step * args.steps / ls_total_s / 1e12 if ls_total_s > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "eaqhm_ls_kernel", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+    # HBM traffic of that kernel: not measurable from inside this process; taken from the committed rocprofv3 PMC
+    # passes of this same command (profiles/r01_final/pmc_hbm_traffic.json), N=1 workload only
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm_traffic.json")
+    if world == 1 and reps == 1 and os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("eaqhm_ls_tile_kernel", {}).get("hbm_bytes_per_launch_fetch_doubled")
+    roofline = {"bound": "mfma", "kernel": "eaqhm_ls_tile_kernel", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final)",
+                "algorithmic_bytes_per_launch": float(np.sum(8 * N) + 32 * np.sum(2 * plan.frame_K[eng.f_lo:eng.f_hi] + 1)),
                 "flops_per_launch_mean": flops_step / max(launches_per_step, 1),
                 "launch_ms_mean": float(np.mean(ls_ms)) if ls_ms else None,
                 "launches_timed": len(ls_ms),

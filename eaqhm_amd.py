@@ -10,3 +10,7 @@ _spec = importlib.util.spec_from_file_location("eaqhm_amd", os.path.join(_dir, "
 _mod = importlib.util.module_from_spec(_spec)
 sys.modules["eaqhm_amd"] = _mod
 _spec.loader.exec_module(_mod)
+
+if __name__ == "__main__":  # python eaqhm_amd.py file.wav --gender female
+    from eaqhm_amd.cli import main as _main
+    raise SystemExit(_main())

@@ -246,3 +246,37 @@ def test_against_oracle_seeded_signal(amd, params):
     assert np.abs(fin["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
     assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
     assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= TOL_PH_RAD
+
+
+def test_entry_point_with_own_swipe(amd, sa19_golden):
+    """The complete drop-in call — wav in, (s_recon, SRER, DetComponents, time) out — with the pitch track
+    estimated by the package's own SWIPE' restatement (no fixture)."""
+    s_recon, SRER, det, T = amd.eaQHMAnalysisAndSynthesis(os.path.join(GOLDEN, "SA19.WAV"), "female", maxAdpt=2,
+                                                         printPrompts=False, loadingScreen=False)
+    assert np.abs(np.array(SRER) - sa19_golden["SRER"][:3]).max() < TOL_SRER_DB
+    assert len(det) == 4233 and s_recon.shape == (63488,)
+
+
+def test_option_paths_against_oracle(amd, tmp_path):
+    """fc > 0 (high-pass pre-filter, functions.py:90-91), partials > 0 (:117-118), tuple gender (:95-97) and a
+    non-default step: host-side options that only change the kernels' inputs."""
+    import eaqhm_oracle as O
+    from scipy.io import wavfile
+    from eaqhm_amd.swipe import swipep
+    from eaqhm_amd.synth import synth_speech_int16
+    fs = 16000
+    x = synth_speech_int16(0.8, fs)
+    path = str(tmp_path / "opt.wav")
+    wavfile.write(path, fs, x)
+    gender, fc, partials, step = (150, 320), 60, 25, 12
+    s_recon, SRER, det, _ = amd.eaQHMAnalysisAndSynthesis(path, gender, step=step, maxAdpt=2, fc=fc,
+                                                         partials=partials, printPrompts=False)
+    s = O.ellip_filter(x / 32768.0, fs, fc)
+    track = swipep(s, fs, list(gender))
+    grid = O.get_linear(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    ti5, sp, vo, fstep = O.voiced_unvoiced_frames(s, fs, gender)
+    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=gender[0], maxAdpt=2, step=step, partials=partials)
+    assert len(SRER) == len(ref["SRER"])
+    assert np.abs(np.array(SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
+    assert np.abs(s_recon - ref["s_recon"]).max() <= 1e-9
+    assert np.array_equal([d.isVoiced for d in det], ref["isVoiced"])

@@ -157,3 +157,28 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert np.abs(got["am"] - ref["am"]).max() < 1e-12 and np.abs(got["fm"] - ref["fm"]).max() < 1e-7
     assert np.abs(got["pk"] - ref["pk"]).max() < 1e-9 and np.abs(got["a0"] - ref["a0"]).max() < 1e-12
     assert 0 < int(got["n_frames_rank0"]) < ref["n_ls_frames"]      # rank 0 analysed only its share
+
+
+def test_swipe_matches_reference_tracks(sa19_golden, sa19_signal):
+    """Host SWIPE' restatement (swipe.py) against the tracks the reference's SWIPE.py produced."""
+    from eaqhm_amd.swipe import swipep
+    fs, s = sa19_signal
+    tr = swipep(s, fs, [160, 300])
+    ref = sa19_golden["swipe_track"]
+    assert tr.shape == ref.shape and np.abs(tr[:, 0] - ref[:, 0]).max() == 0
+    assert np.abs(tr[:, 1] - ref[:, 1]).max() < 1e-9 and np.abs(tr[:, 2] - ref[:, 2]).max() < 1e-12
+    g = load_golden("synth16k_2s_adpt3.npz")
+    tr = swipep(g["wav_int16"] / 32768.0, 16000, [160, 300])
+    assert np.abs(tr[:, 1] - g["swipe_track"][:, 1]).max() < 1e-9
+
+
+def test_swipe_on_tiled_signal_matches_prep_fixture():
+    """SA19 tiled x2 (the bench workload family): SWIPE' + 5 ms resampling against the fixture grid."""
+    from scipy.io import wavfile
+    from eaqhm_amd import prologue
+    from eaqhm_amd.swipe import swipep
+    fs, x = wavfile.read(os.path.join(GOLDEN, "SA19.WAV"))
+    s = np.tile(x, 2) / 32768.0
+    grid = prologue.resample_track(swipep(s, fs, [160, 300]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    ref = load_golden("prep_fixtures.npz")["sa19x2_f0s_5ms"]
+    assert grid.shape[0] == ref.shape[0] and np.abs(grid[:, 1] - ref[:, 1]).max() < 1e-9
