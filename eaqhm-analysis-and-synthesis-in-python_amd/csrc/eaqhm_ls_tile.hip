@@ -196,8 +196,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   double* Xre = U;
   double* Xim = Xre + (size_t)TS * ldx_max;
   const size_t usize_g = (size_t)2 * TS * ldx_max;
-  double* ci = U + usize_g;                          // [48][CI_STRIDE]
-  unsigned long long* masks = (unsigned long long*)(ci + (size_t)CI_STRIDE * 48);  // [48][16]
+  double* ci = U + usize_g;                          // [52][CI_STRIDE]
+  unsigned long long* masks = (unsigned long long*)(ci + (size_t)CI_STRIDE * 52);  // [52][16]  (n <= 51 for Kc <= 103)
   double* PanR = U;                                  // [NT][TILE]  published panel tiles, [k][row]
   double* PanI = PanR + TL_NTMAX * TL_TILE;
   double* WtR = PanI + TL_NTMAX * TL_TILE;           // [NT][TILE]  (W^H)[k][j] of every diagonal tile
@@ -539,7 +539,7 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
 static size_t tl_usize_c() {
   return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
 }
-static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 48 + 48 * CI_NCH; }
+static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH; }
 static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
   const size_t c = tl_usize_c(), g = tl_usize_g(TS, ldx_max);
   return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 64 * CI_NCH;

@@ -280,3 +280,40 @@ def test_option_paths_against_oracle(amd, tmp_path):
     assert np.abs(np.array(SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
     assert np.abs(s_recon - ref["s_recon"]).max() <= 1e-9
     assert np.array_equal([d.isVoiced for d in det], ref["isVoiced"])
+
+
+def test_48khz_large_frames():
+    """BASELINE config 5 in miniature: 0.6 s of the synthetic signal at 48 kHz (N up to 901, Kc up to ~300: the
+    frames take the large-frame LS kernel).  Adaptation 0 is pinned against the reference's run; adaptation 1
+    collapses in the reference itself (near-Nyquist unwrap flips) and is only required to be
+    rejected by the stop rule, as in the reference."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    g = load_golden("synth48k_0p6s_adpt1.npz")
+    fs = 48000
+    s = g["wav_int16"] / 32768.0
+    grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    sh = g["ls_shapes_iqhm"]
+    assert np.array_equal(2 * plan.frame_wl + 1, sh[:, 0]) and np.array_equal(2 * plan.frame_K + 1, sh[:, 1])
+    seen = {}
+
+    def hook(a, e):
+        rec = e.records[0][:plan.No_ti].cpu().numpy()
+        seen[a] = rec.copy()
+
+    eng = DeviceAnalysis(s, s, plan, 160, 1)
+    eng.run(on_adaptation=hook)
+    assert abs(eng.SRER[0] - g["SRER"][0]) < TOL_SRER_DB
+    assert len(eng.SRER) == 2 and eng.SRER[1] < eng.SRER[0]
+    ref = unpack_records(g, 0, with_fm=False)
+    K = plan.Kmax
+    am, ph = seen[0][:, :K], seen[0][:, 2 * K:3 * K]
+    assert np.mean((am != 0) == ref["mask"]) >= 0.999
+    both = (am != 0) & ref["mask"]
+    assert np.abs(am[both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    strong = both & (ref["am"] > 1e-6 * ref["am"].max())      # the angle of a vanishing partial is ill-conditioned
+    assert np.abs(wrap(ph[strong] - ref["ph"][strong])).max() <= TOL_PH_RAD
+    assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9

@@ -137,3 +137,18 @@ def test_sa19_full_run(sa19_golden, sa19_signal):
     assert np.abs(r["am"][i, k] - g["det_am"]).max() <= 1e-11
     assert np.abs(r["fm"][i, k] - g["det_fm"]).max() <= 1e-5
     assert np.abs(wrap(r["pk"][i, k] - g["det_pk"])).max() <= 1e-7
+
+
+@pytest.mark.slow
+def test_synth48k_adaptation0():
+    """48 kHz (BASELINE config 5 in miniature: N up to 901, Kc up to ~300).  Adaptation 0 only: adaptation 1
+    collapses in the reference itself (near-Nyquist unwrap flips) and pins nothing."""
+    g = load_golden("synth48k_0p6s_adpt1.npz")
+    s = g["wav_int16"] / 32768.0
+    seen = {}
+    r = O.analyse(s, 48000, g["f0s_5ms"], g["vuv_ti"], g["vuv_isSpeech"], g["vuv_isVoiced"], int(g["frame_step"]),
+                  f0min=160, maxAdpt=0, on_adaptation=lambda a, rec, st: seen.update(rec=rec))
+    assert abs(r["SRER"][0] - g["SRER"][0]) < 1e-8
+    gr = unpack_records(g, 0, with_fm=False)
+    assert np.array_equal(seen["rec"]["am"] != 0, gr["mask"])
+    assert np.abs(seen["rec"]["am"] - gr["am"]).max() <= 1e-10 * gr["am"].max()
