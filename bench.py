@@ -90,6 +90,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else (RCCL prints a version banner to stdout) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,20 +107,23 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("EAQHM_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the RCCL path
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from eaqhm_amd.engine import DeviceAnalysis, FramePlan, Sharding
     reps = args.reps or args.gpus
     fs, s, grid, frames, fstep = load_workload(reps)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
-    shard = Sharding(rank, world, dist.group.WORLD if world > 1 else None)
+    shard = Sharding(rank, world, dist.group.WORLD if use_dist else None)
     eng = DeviceAnalysis(s, s, plan, 160, args.max_adpt, device_index=local, shard=shard)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +142,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt, float(frames_done)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         tmax = tt[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt[1:].clone()
@@ -184,9 +192,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -64,6 +64,7 @@ class Sharding:
 
     def __init__(self, rank=0, world=1, group=None):
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.collective = group is not None      # a 1-rank group still goes through the collectives (rehearsal)
 
     def chunk(self, n_instants):
         return -(-n_instants // self.world)
@@ -75,14 +76,14 @@ class Sharding:
 
     def all_gather_rows(self, buf, n_instants):
         """In-place all-gather: every rank contributes rows [rank*chunk, (rank+1)*chunk) of `buf`."""
-        if self.world == 1:
+        if not self.collective:
             return
         import torch.distributed as dist
         c = self.chunk(n_instants)
         dist.all_gather_into_tensor(buf, buf[self.rank * c:(self.rank + 1) * c], group=self.group)
 
     def all_reduce_sum(self, t):
-        if self.world == 1:
+        if not self.collective:
             return
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -210,7 +211,7 @@ class DeviceAnalysis:
         e1 = self._mark()
         if self.profile:
             self.timeline.append((a, "post", e0, e1))
-        if sh.world == 1:
+        if not sh.collective:
             return float(self.sums[3].item())   # the one device->host read of the adaptation
         red = self.sums[:2].clone()
         sh.all_reduce_sum(red)
@@ -260,7 +261,7 @@ class DeviceAnalysis:
         s_recon and its own instants of the phases; they are merged here, once, outside the loop.)"""
         p, K, sh = self.plan, self.plan.Kmax, self.shard
         s_hat, ph = self.s_hat[1], self.ph_knot[1]
-        if sh.world > 1:
+        if sh.collective:
             s_hat = s_hat.clone()
             s_hat[:self.s_lo] = 0
             s_hat[self.s_hi:] = 0
