@@ -333,6 +333,41 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The third inner seam as a stand-alone entry: phase_integr_interpolation(fm_recon, ph_recon, indices)
+// (functions.py:537-575) for arbitrary knot spacing.  One thread per sample of [knots[0], knots[m-1]]; the
+// sample's interval is found by binary search; each interval is integrated in the reference's summation
+// order (cumulative sum of the instantaneous frequency, shifted to start at the analysed phase, minus the
+// cumulative sine bump that closes the phase error at the next knot).  The shared knot of two intervals takes
+// the value of the LATER interval (its first sample), the very last knot keeps the integrated value.
+extern "C" __global__ void eaqhm_phase_integrate_kernel(const double* __restrict__ omega, const double* __restrict__ ph,
+                                                        const int* __restrict__ knots, int m, double* __restrict__ out) {
+  const int first = knots[0], last = knots[m - 1];
+  const int t = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > last) return;
+  int lo = 0, hi = m - 1;  // interval i with knots[i] <= t < knots[i+1]  (t == last -> i = m-2)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (knots[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int i0 = knots[lo], i1 = knots[lo + 1], D = i1 - i0, r = t - i0;
+  double acc = omega[i0], sr = acc;
+  for (int u = 1; u <= D; ++u) {
+    acc += omega[i0 + u];
+    if (u == r) sr = acc;
+  }
+  const double shift = ph[i0] - omega[i0];
+  const double e = (acc + shift) - ph[i1];
+  const double Mr = rint(e / (2.0 * M_PI));
+  const double er = M_PI * (e - 2.0 * M_PI * Mr) / (2.0 * (double)D);
+  double c = 0.0, cr = 0.0;
+  for (int u = 0; u <= D; ++u) {
+    c += sin(M_PI * (double)u / (double)D) * er;
+    if (u == r) cr = c;
+  }
+  out[t - first] = (sr + shift) - cr;
+}
 }  // namespace eaqhm
 
 using namespace eaqhm;
@@ -374,6 +409,18 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, (double)(s_hi - s_lo),
                      std_det, sums_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return EAQHM_OK;
+}
+
+extern "C" int eaqhm_phase_integrate(eaqhm_ctx* ctx, const double* omega, const double* ph, const int32_t* knots,
+                                     int32_t n_knots, int32_t first, int32_t last, double* out) {
+  if (!ctx) return EAQHM_EINVAL;
+  if (!omega || !ph || !knots || !out || n_knots < 2 || last <= first)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_phase_integrate: bad argument");
+  const int n = last - first + 1;
+  hipLaunchKernelGGL(eaqhm_phase_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, omega, ph, knots,
+                     n_knots, out);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

@@ -345,7 +345,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       for (int sl = 0; sl < NS; ++sl) {
         if (!live[sl]) continue;
         const int ca = 16 * tP[sl], cb = 16 * tQ[sl];
-#pragma unroll 2
+#pragma clang loop unroll(disable)
         for (int ks = 0; ks < TS / 4; ++ks) {
           const int row = 4 * ks + lq;
           const int sw = (lcol + (row >> 1)) & 15;

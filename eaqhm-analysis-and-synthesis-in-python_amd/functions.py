@@ -6,6 +6,7 @@
         -> (s_recon, SRER, DetComponents, endTime)                      [functions.py:35-418]
     iqhmLS_complexamps(s, f0range, window, fs)   -> (amplitudes, slopes) [functions.py:420-470]
     eaqhmLS_complexamps(s, am, fm, window, fs)   -> (amplitudes, slopes) [functions.py:472-535]
+    phase_integr_interpolation(fm_recon, ph_recon, indices) -> pm_final  [functions.py:537-575]
 
 Same names, argument meaning, defaults, return shapes and error behaviour (Python exceptions).
 There is no CPU path: without the HIP library or a GPU every call raises `HipUnavailable`.
@@ -158,3 +159,23 @@ def iqhmLS_complexamps(s, f0range, window, fs: int):
 def eaqhmLS_complexamps(s, am, fm, window, fs):
     """functions.py:472-535 on the GPU: returns (amplitudes, slopes), each (K, 1) complex128."""
     return _ls_explicit(s, am, fm, None, window, fs)
+
+
+def phase_integr_interpolation(fm_recon, ph_recon, indices):
+    """functions.py:537-575 on the GPU: phase interpolation by integration of the instantaneous frequency
+    (`fm_recon` already in rad/sample, as the driver passes it) between the knots `indices`; returns the dense
+    phase on indices[0]..indices[-1]."""
+    import torch
+    c = _ctx()
+    om = _column(fm_recon)
+    ph = _column(ph_recon)
+    kn = np.ascontiguousarray(np.asarray(indices).reshape(-1), dtype=np.int32)
+    if len(om) != len(ph):
+        raise ValueError("fm_recon and ph_recon lengths differ")
+    if len(kn) < 2 or np.any(np.diff(kn) <= 0) or kn[0] < 0 or kn[-1] >= len(om):
+        raise ValueError("indices must be at least two ascending sample positions inside the arrays")
+    dev = c.device
+    out = torch.zeros(int(kn[-1] - kn[0] + 1), dtype=torch.float64, device=dev)
+    c.phase_integrate(torch.as_tensor(om, device=dev), torch.as_tensor(ph, device=dev), torch.as_tensor(kn, device=dev),
+                      len(kn), int(kn[0]), int(kn[-1]), out)
+    return out.cpu().numpy()

@@ -26,6 +26,7 @@ SYMBOLS = (
     ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _I32, _I32, _I32, _F64, _F64, _P, _P, _P]),
     ("eaqhm_ls_explicit", C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _P, _F64, _P, _P]),
+    ("eaqhm_phase_integrate", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     ("eaqhm_spline_solve", C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     ("eaqhm_eval_synth", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F64, _I64, _I64, _I64, _I64, _I64, _P, _F64,
                                     _P, _P, _P, _P, _P, _P]),
@@ -145,6 +146,9 @@ class Context:
     def ls_explicit(self, s, N, am, fm, f0range, Kc, window, fs, out_amp, out_slope):
         self._ck(self.lib.eaqhm_ls_explicit(self.h, _ptr(s), N, _ptr(am), _ptr(fm), _ptr(f0range), Kc, _ptr(window),
                                             float(fs), _ptr(out_amp), _ptr(out_slope)))
+
+    def phase_integrate(self, omega, ph, knots, n_knots, first, last, out):
+        self._ck(self.lib.eaqhm_phase_integrate(self.h, _ptr(omega), _ptr(ph), _ptr(knots), n_knots, first, last, _ptr(out)))
 
     def spline_solve(self, records, No_ti, Kmax, step, code, mom):
         self._ck(self.lib.eaqhm_spline_solve(self.h, _ptr(records), No_ti, Kmax, step, _ptr(code), _ptr(mom)))

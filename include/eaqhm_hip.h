@@ -109,6 +109,13 @@ int eaqhm_ls_explicit(eaqhm_ctx* ctx, const double* s, int32_t N, const double* 
                       const double* f0range, int32_t Kc, const double* window, double fs, double* out_amp,
                       double* out_slope);
 
+/* the third inner seam, stand-alone ---------------------------------------------------------------
+ * phase_integr_interpolation(fm_recon, ph_recon, indices) (functions.py:537-575): `omega` = 2*pi/fs * fm_recon
+ * and `ph` are dense columns, `knots` (int32[n_knots], ascending, any spacing) the knot samples with
+ * first = knots[0], last = knots[n_knots-1]; out = double[last-first+1], the dense phase on [first, last]. */
+int eaqhm_phase_integrate(eaqhm_ctx* ctx, const double* omega, const double* ph, const int32_t* knots,
+                          int32_t n_knots, int32_t first, int32_t last, double* out);
+
 /* interpolation stage 1: segments + spline systems ---------------------------------------------------
  * Replaces the knot bookkeeping and the not-a-knot cubic solves of functions.py:340 (a0, all instants)
  * and :346-371 (per harmonic: runs of consecutive accepted instants, cubic through the knots).

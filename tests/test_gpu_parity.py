@@ -55,6 +55,22 @@ def test_ls_seams_sa19_frames(amd, sa19_golden):
         assert relerr(a, g[p + "amp"]) < 1e-8 and relerr(b, g[p + "slope"]) < 1e-8
 
 
+def test_phase_integration_seam(amd):
+    """phase_integr_interpolation (functions.py:537-575) against the reference's output, plus uneven knots vs the oracle."""
+    import eaqhm_oracle as O
+    u = load_golden("unit_vectors.npz")
+    p = amd.phase_integr_interpolation(u["pii_fm"], u["pii_ph"], u["pii_knots"])
+    assert p.shape == u["pii_out"].shape and np.abs(p - u["pii_out"]).max() <= 1e-12
+    rng = np.random.default_rng(3)
+    om = 2 * np.pi / 16000 * (300 + 50 * rng.standard_normal(200))
+    kn = np.array([5, 20, 33, 64, 65, 120, 199])
+    ph = np.zeros(200)
+    ph[kn] = rng.uniform(-np.pi, np.pi, len(kn))
+    assert np.abs(amd.phase_integr_interpolation(om, ph, kn) - O.phase_integr_interpolation(om, ph, kn)).max() <= 1e-12
+    with pytest.raises(ValueError):
+        amd.phase_integr_interpolation(om, ph, [10, 5])
+
+
 def test_ls_seam_errors(amd):
     with pytest.raises(ValueError):
         amd.iqhmLS_complexamps(np.zeros(11), np.arange(3.0), np.ones(10), 16000)
