@@ -1,0 +1,67 @@
+"""GPU test of the frame-sharded path with the REAL kernels: two processes share the one GPU of the test box
+(NCCL needs one device per rank, so the two collectives are staged through the host over gloo here — the
+buffers, ranges, halos and kernels are exactly those of the multi-GPU run)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import eaqhm_amd  # noqa: F401
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan, Sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class HostStaged(Sharding):
+        def all_gather_rows(self, buf, n_instants):
+            c = self.chunk(n_instants)
+            host = buf.cpu()
+            dist.all_gather_into_tensor(host, host[self.rank * c:(self.rank + 1) * c].clone(), group=self.group)
+            buf.copy_(host)
+
+        def all_reduce_sum(self, t):
+            host = t.cpu()
+            dist.all_reduce(host, group=self.group)
+            t.copy_(host)
+
+    g = load_golden("sa19_female_default.npz")
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 480)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    eng = DeviceAnalysis(s, s, plan, 160, 5, shard=HostStaged(rank, world, dist.group.WORLD))
+    eng.run()
+    fin = eng.final_arrays()
+    if rank == 0:
+        np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, **fin)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_matches_reference(tmp_path, sa19_golden):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 300, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = sa19_golden
+    assert len(got["SRER"]) == 6 and np.abs(got["SRER"] - g["SRER"]).max() < 1e-6
+    assert np.abs(got["s_recon"] - g["s_recon"]).max() <= 1e-9
+    assert 0 < int(got["frames_rank0"]) < 6 * 4169
+    cells = g["det_cells"]
+    i, k = cells[:, 0], cells[:, 1]
+    ok = got["am"][i, k] != 0
+    assert ok.mean() > 0.999
+    assert np.abs(got["am"][i, k][ok] - g["det_am"][ok]).max() <= 1e-8 * g["det_am"].max()
+    assert np.abs(got["fm"][i, k][ok] - g["det_fm"][ok]).max() <= 1e-3
+    d = (got["pk"][i, k][ok] - g["det_pk"][ok] + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() <= 1e-5
