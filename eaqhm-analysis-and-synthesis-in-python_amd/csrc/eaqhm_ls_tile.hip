@@ -58,20 +58,50 @@ __device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* A
   const double eps = 10e-5;  // functions.py:517
   const int nch = (N + 63) >> 6;
   const long long t0 = (long long)c - wl;
-  for (int it = wave; it < n * nch; it += TL_WAVES) {  // pass 1: nonzero masks of every (slot, chunk)
-    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-    const double f = (t < N) ? track_fm(A, mycols[j], t0 + t, c, seeds) : 0.0;
-    const unsigned long long m = __ballot(f != 0.0);
-    if (lane == 0) masks[j * CI_NCH + ch] = m;
+  // pass 1: nonzero masks of every (slot, chunk); four items in flight per wave to overlap the load latencies
+  for (int it0 = wave; it0 < n * nch; it0 += 4 * TL_WAVES) {
+    double fv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int it = it0 + q * TL_WAVES;
+      fv[q] = 0.0;
+      if (it < n * nch) {
+        const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+        if (t < N) fv[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int it = it0 + q * TL_WAVES;
+      const unsigned long long m = __ballot(fv[q] != 0.0);
+      if (it < n * nch && lane == 0) {
+        const int j = it / nch, ch = it - j * nch;
+        masks[j * CI_NCH + ch] = m;
+      }
+    }
   }
   __syncthreads();
-  for (int it = wave; it < n * nch; it += TL_WAVES) {  // pass 2: fill, scan, store
+  for (int it0 = wave; it0 < n * nch; it0 += 2 * TL_WAVES) {  // pass 2: fill, scan, store (two items in flight)
+   double f2[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
+#pragma unroll
+   for (int q = 0; q < 2; ++q) {
+     const int it = it0 + q * TL_WAVES;
+     if (it < n * nch) {
+       const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+       if (t < N) {
+         f2[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
+         a2[q] = track_am(A, mycols[j], t0 + t, c, seeds);
+       }
+     }
+   }
+#pragma unroll
+   for (int q = 0; q < 2; ++q) {
+    const int it = it0 + q * TL_WAVES;
+    if (it >= n * nch) continue;
     const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
     const int k = mycols[j];
-    double f = 0.0, a = 0.0;
+    double f = f2[q], a = a2[q];
     if (t < N) {
-      f = track_fm(A, k, t0 + t, c, seeds);
-      a = track_am(A, k, t0 + t, c, seeds);
       if (f == 0.0) {  // nearest nonzero samples on both sides, from the masks (functions.py:251-278)
         int p = -1, q = -1;
         {
@@ -118,6 +148,7 @@ __device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* A
       ci[j * CI_STRIDE + 18] = cs;
       ci[j * CI_STRIDE + 19] = sn;
     }
+   }
   }
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
