@@ -243,6 +243,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
   double* sh = xs + 4 * A.Kcmax;                     // 16
   double* win = sh + 16;                             // [64*CI_NCH] analysis window of the frame
+  double* sig = win + 64 * CI_NCH;                   // [64*CI_NCH] signal window of the frame
 
   const int Npad = ((A.Nmax + 63) >> 6) << 6;
   double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
@@ -277,7 +278,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
     for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
-    for (int t = tid; t < N; t += nt_thr) win[t] = window_value(A.mode == 0, t, N);
+    for (int t = tid; t < N; t += nt_thr) {
+      win[t] = window_value(A.mode == 0, t, N);
+      sig[t] = A.s[(size_t)(c - wl) + t];
+    }
     __syncthreads();
     if (A.mode == 1) fill_columns_par(A, Qs, Rs, Npad, ci, masks, mycols, n, N, mid, c, wl, seeds, lane, wave);
     STAMP(0);
@@ -352,13 +356,14 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
         xr[cpos] = pvr;      xi[cpos] = pvi;      xr[cneg] = nvr;      xi[cneg] = nvi;
         xr[spos] = nv * pvr; xi[spos] = nv * pvi; xr[sneg] = nv * nvr; xi[sneg] = nv * nvi;
       }
-#pragma clang loop unroll(disable)
-      for (int row = tid; row < TS; row += nt_thr) {
+      // DC / signal columns: one thread per chunk row, spread over the waves (lanes 0, 16, 32, 48)
+      if ((tid & 15) == 0 && (tid >> 4) < TS) {
+        const int row = tid >> 4;
         const int e = e0 + (row >> 1);
         const int t = (row & 1) ? (N - 1 - e) : (e - 1);
         const bool ok = (e < npairs) && (t >= 0);
         const double w = ok ? win[t] : 0.0;
-        const double sval = ok ? A.s[(size_t)(c - wl) + t] : 0.0;
+        const double sval = ok ? sig[t] : 0.0;
         const double nn = (double)(t - mid);
         const int el = row >> 1;
         double* xr = Xre + row * ldx;
@@ -366,10 +371,17 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
         xr[XCOL(n, el)] = w;               xi[XCOL(n, el)] = 0.0;            // DC column
         xr[XCOL(Kc + n, el)] = w * nn;     xi[XCOL(Kc + n, el)] = 0.0;       // its slope copy
         xr[XCOL(2 * Kc, el)] = w * sval;   xi[XCOL(2 * Kc, el)] = 0.0;       // signal column
-        if (!ok) {  // rows beyond the window (tail of the last chunk, the virtual sample u = -1): all zero
-          for (int q = 0; q < Ms; ++q) { xr[XCOL(q, el)] = 0.0; xi[XCOL(q, el)] = 0.0; }
+      }
+      // rows beyond the window (the virtual sample u = -1 of the first chunk, the tail of the last chunk): zero
+      if (e0 == 0 || e0 + PE > npairs) {
+        for (int q = tid; q < TS * 16 * nt; q += nt_thr) {
+          const int row = q / (16 * nt), col = q - row * (16 * nt);
+          const int e = e0 + (row >> 1);
+          const int t = (row & 1) ? (N - 1 - e) : (e - 1);
+          if (e >= npairs || t < 0) { Xre[row * ldx + col] = 0.0; Xim[row * ldx + col] = 0.0; }
         }
       }
+      STAMP(12);
       __syncthreads();
       STAMP(1);
 #pragma unroll
@@ -573,7 +585,7 @@ static size_t tl_usize_c() {
 static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH; }
 static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
   const size_t c = tl_usize_c(), g = tl_usize_g(TS, ldx_max);
-  return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 64 * CI_NCH;
+  return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 2 * 64 * CI_NCH;
 }
 
 // the tile variant needs its LDS budget (which grows with Kmax through the solution vector) to fit

@@ -11,7 +11,7 @@ eng.ctx.set_option(2, 1)
 eng.run()
 eng.reset(); 
 d = eng.ctx.debug_read()
-names = ["setup+A1", "basis build", "contraction", "(fact tail)", "backsubst", "record", "publish diag", "trsm", "update", "-", "diag_coop"]
+names = ["setup+A1", "build: barrier wait", "contraction", "(fact tail)", "backsubst", "record", "publish diag", "trsm", "update", "-", "diag_coop", "build: items (thread 0)", "build: rows (thread 0)"]
 tot = sum(d[:6])
 for n, v in zip(names, d):
     print("%-20s %12d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
