@@ -517,18 +517,22 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       for (int q = tid; q < 4 * Kc; q += nt_thr) xs[q] = 0.0;
       __syncthreads();  // y gathered
       for (int P = nt - 1; P >= 0; --P) {
-        if (tid < 16) {  // x_P = W_PP^H z_P : row tid of (W^H)
-          const double* wr = WtR + P * TL_TILE + tid * TL_LD;
-          const double* wi = WtI + P * TL_TILE + tid * TL_LD;
+        if (tid < 256) {  // x_P = W_PP^H z_P : thread (i, k) takes one term of row i, 16-lane shuffle reduction
+          const int i = tid >> 4, k = tid & 15;
           double xr = 0, xi = 0;
-          for (int k = tid; k < 16; ++k) {
+          if (k >= i) {   // W^H is upper triangular
+            const double wr = WtR[P * TL_TILE + i * TL_LD + k], wi = WtI[P * TL_TILE + i * TL_LD + k];
             const double zr = zv[2 * (16 * P + k)], zi = zv[2 * (16 * P + k) + 1];
-            xr += wr[k] * zr - wi[k] * zi;
-            xi += wr[k] * zi + wi[k] * zr;
+            xr = wr * zr - wi * zi;
+            xi = wr * zi + wi * zr;
           }
-          xv[2 * tid] = xr; xv[2 * tid + 1] = xi;
-          const int q = 16 * P + tid;   // natural order: amplitudes then slopes
-          if (q < 2 * Kc) { xs[2 * q] = xr; xs[2 * q + 1] = xi; }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { xr += __shfl_xor(xr, o); xi += __shfl_xor(xi, o); }
+          if (k == 0) {
+            xv[2 * i] = xr; xv[2 * i + 1] = xi;
+            const int q = 16 * P + i;   // natural order: amplitudes then slopes
+            if (q < 2 * Kc) { xs[2 * q] = xr; xs[2 * q + 1] = xi; }
+          }
         }
         __syncthreads();
 #pragma unroll
