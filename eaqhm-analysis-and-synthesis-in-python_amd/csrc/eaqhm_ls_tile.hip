@@ -58,75 +58,34 @@ __device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* A
   const double eps = 10e-5;  // functions.py:517
   const int nch = (N + 63) >> 6;
   const long long t0 = (long long)c - wl;
-  // pass 1: nonzero masks of every (slot, chunk); four items in flight per wave to overlap the load latencies
-  for (int it0 = wave; it0 < n * nch; it0 += 4 * TL_WAVES) {
-    double fv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int it = it0 + q * TL_WAVES;
-      fv[q] = 0.0;
-      if (it < n * nch) {
-        const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-        if (t < N) fv[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
+  // One item = (slot j, 64-sample chunk ch).  `fill` bridges the zeros of the item from the masks of the whole
+  // slot; it is only legal once every chunk of the slot has published its mask.
+  auto finish_item = [&](int j, int ch, double f, double a, bool fill) {
+    const int t = (ch << 6) + lane, k = mycols[j];
+    if (fill && t < N && f == 0.0) {  // nearest nonzero samples on both sides (functions.py:251-278)
+      int p = -1, q = -1;
+      {
+        unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+        int cc = ch;
+        while (m == 0ull && cc > 0) { --cc; m = masks[j * CI_NCH + cc]; }
+        if (m != 0ull) p = (cc << 6) + 63 - __clzll((long long)m);
       }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int it = it0 + q * TL_WAVES;
-      const unsigned long long m = __ballot(fv[q] != 0.0);
-      if (it < n * nch && lane == 0) {
-        const int j = it / nch, ch = it - j * nch;
-        masks[j * CI_NCH + ch] = m;
+      {
+        unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
+        int cc = ch;
+        while (m == 0ull && cc < nch - 1) { ++cc; m = masks[j * CI_NCH + cc]; }
+        if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
       }
-    }
-  }
-  __syncthreads();
-  for (int it0 = wave; it0 < n * nch; it0 += 2 * TL_WAVES) {  // pass 2: fill, scan, store (two items in flight)
-   double f2[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
-#pragma unroll
-   for (int q = 0; q < 2; ++q) {
-     const int it = it0 + q * TL_WAVES;
-     if (it < n * nch) {
-       const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-       if (t < N) {
-         f2[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
-         a2[q] = track_am(A, mycols[j], t0 + t, c, seeds);
-       }
-     }
-   }
-#pragma unroll
-   for (int q = 0; q < 2; ++q) {
-    const int it = it0 + q * TL_WAVES;
-    if (it >= n * nch) continue;
-    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-    const int k = mycols[j];
-    double f = f2[q], a = a2[q];
-    if (t < N) {
-      if (f == 0.0) {  // nearest nonzero samples on both sides, from the masks (functions.py:251-278)
-        int p = -1, q = -1;
-        {
-          unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
-          int cc = ch;
-          while (m == 0ull && cc > 0) { --cc; m = masks[j * CI_NCH + cc]; }
-          if (m != 0ull) p = (cc << 6) + 63 - __clzll((long long)m);
-        }
-        {
-          unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
-          int cc = ch;
-          while (m == 0ull && cc < nch - 1) { ++cc; m = masks[j * CI_NCH + cc]; }
-          if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
-        }
-        if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
-          f = track_fm(A, k, t0 + q, c, seeds); a = track_am(A, k, t0 + q, c, seeds);
-        } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
-          f = track_fm(A, k, t0 + p, c, seeds); a = track_am(A, k, t0 + p, c, seeds);
-        } else {             // interior gap: linear (functions.py:277-278)
-          const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
-          const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
-          const double dx = (double)(q - p), xx = (double)(t - p);
-          f = ((f1v - f0v) / dx) * xx + f0v;
-          a = ((a1v - a0v) / dx) * xx + a0v;
-        }
+      if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
+        f = track_fm(A, k, t0 + q, c, seeds); a = track_am(A, k, t0 + q, c, seeds);
+      } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
+        f = track_fm(A, k, t0 + p, c, seeds); a = track_am(A, k, t0 + p, c, seeds);
+      } else {             // interior gap: linear (functions.py:277-278)
+        const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
+        const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
+        const double dx = (double)(q - p), xx = (double)(t - p);
+        f = ((f1v - f0v) / dx) * xx + f0v;
+        a = ((a1v - a0v) / dx) * xx + a0v;
       }
     }
     double sc = f;  // inclusive scan over the wave
@@ -148,7 +107,50 @@ __device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* A
       ci[j * CI_STRIDE + 18] = cs;
       ci[j * CI_STRIDE + 19] = sn;
     }
-   }
+  };
+  // pass 1 (every item, two in flight per wave): optimistic — load, publish the nonzero mask, scan and store
+  // as if the window had no gaps; a slot with a zero anywhere in its window is flagged for pass 2
+  int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
+  for (int j = threadIdx.x; j < n; j += blockDim.x) gappy[j] = 0;
+  __syncthreads();
+  for (int it0 = wave; it0 < n * nch; it0 += 2 * TL_WAVES) {
+    double f2[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int it = it0 + q * TL_WAVES;
+      if (it < n * nch) {
+        const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+        if (t < N) {
+          f2[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
+          a2[q] = track_am(A, mycols[j], t0 + t, c, seeds);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int it = it0 + q * TL_WAVES;
+      if (it >= n * nch) continue;
+      const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+      const unsigned long long m = __ballot(f2[q] != 0.0);
+      const unsigned long long valid = __ballot(t < N);
+      if (lane == 0) {
+        masks[j * CI_NCH + ch] = m;
+        if (m != valid) gappy[j] = 1;
+      }
+      finish_item(j, ch, f2[q], a2[q], false);
+    }
+  }
+  __syncthreads();
+  // pass 2 (rare): redo the slots that had gaps, now that all their masks are known
+  for (int it = wave; it < n * nch; it += TL_WAVES) {
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+    if (!gappy[j]) continue;
+    double f = 0.0, a = 0.0;
+    if (t < N) {
+      f = track_fm(A, mycols[j], t0 + t, c, seeds);
+      a = track_am(A, mycols[j], t0 + t, c, seeds);
+    }
+    finish_item(j, ch, f, a, true);
   }
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -586,7 +588,7 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
 static size_t tl_usize_c() {
   return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
 }
-static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH; }
+static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH + 32; }
 static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
   const size_t c = tl_usize_c(), g = tl_usize_g(TS, ldx_max);
   return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 2 * 64 * CI_NCH;
