@@ -17,6 +17,7 @@ struct LsArgs {
   double* records; double* raw_amp; double* raw_slope;
   double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
   int* work_counter;  // dynamic frame queue; may be null
+  const unsigned char* gapflag;  // [n_frames][Kmax] window-has-a-zero flags (tile variant, mode 1)
   unsigned long long* debug;  // phase stamps (16 x u64)
 };
 

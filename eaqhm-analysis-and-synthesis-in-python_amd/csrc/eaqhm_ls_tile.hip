@@ -48,21 +48,49 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   Q = x - P * (P + 1) / 2;
 }
 // ---- Phase A1 -----------------------------------------------------------------------------------------------
-//   Qloc[j][t]  scan of fm inside its 64-sample chunk         (global scratch, row stride Npad)
-//   Af[j][t]    gap-filled am                                  (global scratch)
-//   ci          per-slot info in LDS, so that  F(u) - F(mid) = Qloc[j][u] + carry[j][u>>6] - qmid[j]
-//               and  ratio(u) = (eps + Af[j][u]) * ainv[j]      (functions.py:508-518)
-__device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* Af, int Npad, double* ci,
-                                        unsigned long long* masks, const int* mycols, int n, int N, int mid, int c,
-                                        int wl, bool seeds, int lane, int wave) {
+// Per-slot set-up.  A slot whose track has no zero inside the frame's window (flag from eaqhm_ls_gapflag_kernel;
+// the common case) needs nothing but its centre values: the basis build reads the track itself and integrates
+// the frequency on the fly, outwards from the centre.  A slot with gaps gets its window bridged
+// (functions.py:251-278) into the workgroup's scratch rows, which the build then reads instead of the track.
+//   ci[j]: [0] running sum of fm over (mid, mid+d], [1] over [mid-d, mid]  (carried from chunk to chunk),
+//          [17] 1/(am_mid+eps), [18..19] rho = exp(j 2 pi fm_mid / fs)      (functions.py:508-518, :284-285)
+__device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, int Npad, double* ci,
+                                     unsigned long long* masks, int* gappy, const int* mycols, int n, int N, int mid,
+                                     int c, int wl, bool seeds, int lane, int wave, int f) {
   const double eps = 10e-5;  // functions.py:517
   const int nch = (N + 63) >> 6;
   const long long t0 = (long long)c - wl;
-  // One item = (slot j, 64-sample chunk ch).  `fill` bridges the zeros of the item from the masks of the whole
-  // slot; it is only legal once every chunk of the slot has published its mask.
-  auto finish_item = [&](int j, int ch, double f, double a, bool fill) {
-    const int t = (ch << 6) + lane, k = mycols[j];
-    if (fill && t < N && f == 0.0) {  // nearest nonzero samples on both sides (functions.py:251-278)
+  auto centre = [&](int j, double fv, double av) {
+    ci[j * CI_STRIDE + 17] = 1.0 / (av + eps);
+    double sn, cs;
+    sincos_cw((2.0 * M_PI * fv) / A.fs, &sn, &cs);
+    ci[j * CI_STRIDE + 18] = cs;
+    ci[j * CI_STRIDE + 19] = sn;
+  };
+  int anyg = 0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int g = A.gapflag[(size_t)f * A.Kmax + j];
+    gappy[j] = g;
+    anyg |= g;
+    ci[j * CI_STRIDE + 0] = 0.0;
+    ci[j * CI_STRIDE + 1] = 0.0;
+    if (!g) centre(j, track_fm(A, mycols[j], c, c, seeds), track_am(A, mycols[j], c, c, seeds));
+  }
+  if (!__syncthreads_or(anyg)) return;
+  // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
+  for (int it = wave; it < n * nch; it += TL_WAVES) {
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+    if (!gappy[j]) continue;
+    const double fv = (t < N) ? track_fm(A, mycols[j], t0 + t, c, seeds) : 0.0;
+    const unsigned long long m = __ballot(fv != 0.0);
+    if (lane == 0) masks[j * CI_NCH + ch] = m;
+  }
+  __syncthreads();
+  for (int it = wave; it < n * nch; it += TL_WAVES) {
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane, k = mycols[j];
+    if (!gappy[j] || t >= N) continue;
+    double fv = track_fm(A, k, t0 + t, c, seeds), av = track_am(A, k, t0 + t, c, seeds);
+    if (fv == 0.0) {  // nearest nonzero samples on both sides (functions.py:251-278)
       int p = -1, q = -1;
       {
         unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
@@ -77,92 +105,37 @@ __device__ inline void fill_columns_par(const LsArgs& A, double* Qloc, double* A
         if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
       }
       if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
-        f = track_fm(A, k, t0 + q, c, seeds); a = track_am(A, k, t0 + q, c, seeds);
+        fv = track_fm(A, k, t0 + q, c, seeds); av = track_am(A, k, t0 + q, c, seeds);
       } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
-        f = track_fm(A, k, t0 + p, c, seeds); a = track_am(A, k, t0 + p, c, seeds);
+        fv = track_fm(A, k, t0 + p, c, seeds); av = track_am(A, k, t0 + p, c, seeds);
       } else {             // interior gap: linear (functions.py:277-278)
         const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
         const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
         const double dx = (double)(q - p), xx = (double)(t - p);
-        f = ((f1v - f0v) / dx) * xx + f0v;
-        a = ((a1v - a0v) / dx) * xx + a0v;
+        fv = ((f1v - f0v) / dx) * xx + f0v;
+        av = ((a1v - a0v) / dx) * xx + a0v;
       }
     }
-    double sc = f;  // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const double up = __shfl_up(sc, o, 64);
-      if (lane >= o) sc += up;
-    }
-    if (t < N) {
-      Qloc[(size_t)j * Npad + t] = sc;
-      Af[(size_t)j * Npad + t] = a;
-    }
-    if (lane == 63) ci[j * CI_STRIDE + ch] = sc;  // chunk total (turned into carries below)
-    if (t == mid) {
-      ci[j * CI_STRIDE + 16] = sc;                // local scan at mid (carry added below)
-      ci[j * CI_STRIDE + 17] = 1.0 / (a + eps);
-      double sn, cs;
-      sincos_cw((2.0 * M_PI * f) / A.fs, &sn, &cs);
-      ci[j * CI_STRIDE + 18] = cs;
-      ci[j * CI_STRIDE + 19] = sn;
-    }
-  };
-  // pass 1 (every item, two in flight per wave): optimistic — load, publish the nonzero mask, scan and store
-  // as if the window had no gaps; a slot with a zero anywhere in its window is flagged for pass 2
-  int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
-  for (int j = threadIdx.x; j < n; j += blockDim.x) gappy[j] = 0;
-  __syncthreads();
-  for (int it0 = wave; it0 < n * nch; it0 += 2 * TL_WAVES) {
-    double f2[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int it = it0 + q * TL_WAVES;
-      if (it < n * nch) {
-        const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-        if (t < N) {
-          f2[q] = track_fm(A, mycols[j], t0 + t, c, seeds);
-          a2[q] = track_am(A, mycols[j], t0 + t, c, seeds);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int it = it0 + q * TL_WAVES;
-      if (it >= n * nch) continue;
-      const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-      const unsigned long long m = __ballot(f2[q] != 0.0);
-      const unsigned long long valid = __ballot(t < N);
-      if (lane == 0) {
-        masks[j * CI_NCH + ch] = m;
-        if (m != valid) gappy[j] = 1;
-      }
-      finish_item(j, ch, f2[q], a2[q], false);
-    }
+    Qf[(size_t)j * Npad + t] = fv;
+    Af[(size_t)j * Npad + t] = av;
+    if (t == mid) centre(j, fv, av);
   }
   __syncthreads();
-  // pass 2 (rare): redo the slots that had gaps, now that all their masks are known
-  for (int it = wave; it < n * nch; it += TL_WAVES) {
-    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-    if (!gappy[j]) continue;
-    double f = 0.0, a = 0.0;
-    if (t < N) {
-      f = track_fm(A, mycols[j], t0 + t, c, seeds);
-      a = track_am(A, mycols[j], t0 + t, c, seeds);
-    }
-    finish_item(j, ch, f, a, true);
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    double run = 0.0;
-    for (int ch = 0; ch < nch; ++ch) {
-      const double tot = ci[j * CI_STRIDE + ch];
-      ci[j * CI_STRIDE + ch] = run;
-      run += tot;
-    }
-    ci[j * CI_STRIDE + 16] += ci[j * CI_STRIDE + (mid >> 6)];
-  }
-  __syncthreads();
+}
+
+// inclusive sum over each aligned group of 16 lanes (DPP row shifts: a row is 16 lanes, zeros are shifted in)
+template <int CTRL>
+__device__ inline double dpp_row(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double scan16(double x) {
+  x += dpp_row<0x111>(x);  // row_shr:1
+  x += dpp_row<0x112>(x);  // row_shr:2
+  x += dpp_row<0x114>(x);  // row_shr:4
+  x += dpp_row<0x118>(x);  // row_shr:8
+  return x;
 }
 
 // ---- diagonal tile: Cholesky factor L and W = L^-1 of a 16x16 Hermitian positive definite tile, by the whole
@@ -329,7 +302,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       sig[t] = A.s[(size_t)(c - wl) + t];
     }
     __syncthreads();
-    if (A.mode == 1) fill_columns_par(A, Qs, Rs, Npad, ci, masks, mycols, n, N, mid, c, wl, seeds, lane, wave);
+    int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
+    if (A.mode == 1) prepare_slots(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, f);
     STAMP(0);
 
     // system tiles of this wave (compute waves only)
@@ -348,41 +322,50 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     }
 
     // ================= Gramian =================
-    for (int e0 = 0; e0 < npairs; e0 += PE) {
+    // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid, taken from the centre outwards so that the phase
+    // integral of functions.py:508-515 relative to the centre is a running sum
+    const long long t0 = (long long)c - wl;
+    for (int d0 = 0; d0 < npairs; d0 += PE) {
       // logical column cc of chunk rows (2*el, 2*el+1) lives at XCOL(cc, el): the 16 lanes that write one column
       // of 16 different pairs hit 16 different banks, and MFMA operand reads stay conflict-free
 #pragma clang loop unroll(disable)
       for (int idx = tid; idx < 16 * n; idx += nt_thr) {
-        const int el = idx & 15, j = idx >> 4, e = e0 + el;
-        if (e >= npairs || el >= PE) continue;
-        const int u = e - 1, v = N - 1 - e;
+        const int el = idx & 15, j = idx >> 4, d = d0 + el;
+        const bool act = d <= mid;
+        const int u = mid - d - 1, v = mid + d;
         double su = 0, cu = 1, sv, cv;
-        double* xr = Xre + (2 * el) * ldx;
-        double* xi = Xim + (2 * el) * ldx;
-        const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);               // amplitude columns
-        const int spos = XCOL(Kc + n + 1 + j, el), sneg = XCOL(Kc + j, el);     // slope columns (n_t times)
-        const double wv = win[v], nv = (double)(v - mid);
         double pur = 0, pui = 0, nur = 0, nui = 0, pvr, pvi, nvr, nvi;  // positive / negative column values
         if (A.mode == 1) {
-          const double* cj = ci + j * CI_STRIDE;
-          const double qmid = cj[16], ainv = cj[17], pr = cj[18], pi = cj[19];
-          const double* ql = Qs + (size_t)j * Npad;
-          const double* af = Rs + (size_t)j * Npad;
-          const double qu = (u >= 0) ? (ql[u] + cj[u >> 6] - qmid) : -qmid;
-          const double qv = ql[v] + cj[v >> 6] - qmid;
+          double* cj = ci + j * CI_STRIDE;
+          const bool gp = gappy[j] != 0;
+          const size_t trk = (size_t)mycols[j] * A.L + t0;
+          const double* fb = gp ? (Qs + (size_t)j * Npad) : (A.fm_cur + trk);   // bridged copy or the track itself
+          const double* ab = gp ? (Rs + (size_t)j * Npad) : (A.am_cur + trk);
+          // every load of the item up front, indices clamped into the window (results of clamped ones unused)
+          const int dc = act ? d : mid;
+          const double fu1 = fb[mid - dc], fv = fb[mid + dc];
+          const double au = ab[(mid - dc - 1 >= 0) ? (mid - dc - 1) : 0], au1 = ab[mid - dc];
+          const double av = ab[mid + dc], av1 = ab[(mid + dc + 1 < N) ? (mid + dc + 1) : (N - 1)];
+          // F(v) - F(mid) = sum of fm over (mid, v];  F(u) - F(mid) = -sum over [u+1, mid]
+          const double xu = act ? fu1 : 0.0, xv = (act && d >= 1) ? fv : 0.0;
+          const double qv = cj[0] + scan16(xv), qu = -(cj[1] + scan16(xu));
+          if (el == 15) { cj[0] = qv; cj[1] = -qu; }   // carried to the next chunk (read again after two barriers)
+          if (!act) continue;
+          const double ainv = cj[17], pr = cj[18], pi = cj[19];
           sincos_cw((2.0 * M_PI * qu) / A.fs, &su, &cu);
           sincos_cw((2.0 * M_PI * qv) / A.fs, &sv, &cv);
           const double eps = 10e-5;
           // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
           if (u >= 0) {
-            const double ru = (eps + af[u]) * ainv, rv1 = (eps + af[v + 1]) * ainv;
+            const double ru = (eps + au) * ainv, rv1 = (eps + av1) * ainv;
             pur = ru * cu;                    pui = ru * su;
             nur = rv1 * (cv * pr - sv * pi);  nui = rv1 * (cv * pi + sv * pr);
           }
-          const double rv = (eps + af[v]) * ainv, ru1 = (eps + af[u + 1]) * ainv;
+          const double rv = (eps + av) * ainv, ru1 = (eps + au1) * ainv;
           pvr = rv * cv;                      pvi = rv * sv;
           nvr = ru1 * (cu * pr - su * pi);    nvi = ru1 * (cu * pi + su * pr);
         } else {  // adaptation 0: exp(j 2 pi k f0 n / fs), negative column = conjugate (functions.py:453-454)
+          if (!act) continue;
           const double fk = (double)(j + 1) * f0;
           if (u >= 0) {
             sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
@@ -391,6 +374,11 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
           sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
           pvr = cv; pvi = sv; nvr = cv; nvi = -sv;
         }
+        double* xr = Xre + (2 * el) * ldx;
+        double* xi = Xim + (2 * el) * ldx;
+        const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);               // amplitude columns
+        const int spos = XCOL(Kc + n + 1 + j, el), sneg = XCOL(Kc + j, el);     // slope columns (n_t times)
+        const double wv = win[v], nv = (double)(v - mid);
         if (u >= 0) {
           const double wu = win[u], nu = (double)(u - mid);
           pur *= wu; pui *= wu; nur *= wu; nui *= wu;
@@ -405,9 +393,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       // DC / signal columns: one thread per chunk row, spread over the waves (lanes 0, 16, 32, 48)
       if ((tid & 15) == 0 && (tid >> 4) < TS) {
         const int row = tid >> 4;
-        const int e = e0 + (row >> 1);
-        const int t = (row & 1) ? (N - 1 - e) : (e - 1);
-        const bool ok = (e < npairs) && (t >= 0);
+        const int d = d0 + (row >> 1);
+        const int t = (row & 1) ? (mid + d) : (mid - d - 1);
+        const bool ok = (d <= mid) && (t >= 0);
         const double w = ok ? win[t] : 0.0;
         const double sval = ok ? sig[t] : 0.0;
         const double nn = (double)(t - mid);
@@ -418,13 +406,13 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
         xr[XCOL(Kc + n, el)] = w * nn;     xi[XCOL(Kc + n, el)] = 0.0;       // its slope copy
         xr[XCOL(2 * Kc, el)] = w * sval;   xi[XCOL(2 * Kc, el)] = 0.0;       // signal column
       }
-      // rows beyond the window (the virtual sample u = -1 of the first chunk, the tail of the last chunk): zero
-      if (e0 == 0 || e0 + PE > npairs) {
+      // rows beyond the window (the virtual sample u = -1 and the tail of the last chunk): zero
+      if (d0 + PE > mid) {
         for (int q = tid; q < TS * 16 * nt; q += nt_thr) {
           const int row = q / (16 * nt), col = q - row * (16 * nt);
-          const int e = e0 + (row >> 1);
-          const int t = (row & 1) ? (N - 1 - e) : (e - 1);
-          if (e >= npairs || t < 0) { Xre[row * ldx + col] = 0.0; Xim[row * ldx + col] = 0.0; }
+          const int d = d0 + (row >> 1);
+          const int t = (row & 1) ? (mid + d) : (mid - d - 1);
+          if (d > mid || t < 0) { Xre[row * ldx + col] = 0.0; Xim[row * ldx + col] = 0.0; }
         }
       }
       STAMP(12);
@@ -609,6 +597,23 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   }
 }
 
+// Which (frame, slot) windows contain a zero of the frequency track: one wave per slot, whole chip busy, so the
+// persistent kernel below never has to scan windows that need no bridging (the common case).
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_gapflag_kernel(LsArgs A, unsigned char* flags) {
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = A.ncol[f], c = A.frame_c[f], wl = A.frame_wl[f], N = 2 * wl + 1;
+  const bool seeds = A.any_seed && (*A.any_seed != 0);
+  const long long t0 = (long long)c - wl;
+  for (int j = wave; j < n; j += 4) {
+    const int k = A.cols[(size_t)f * A.Kmax + j];
+    bool z = false;
+    for (int t = lane; t < N; t += 64) z |= (track_fm(A, k, t0 + t, c, seeds) == 0.0);
+    const unsigned long long m = __ballot(z);
+    // a seeded slot 0 (functions.py:209-210) shows substituted values: route it through the bridged copy too
+    if (lane == 0) flags[(size_t)f * A.Kmax + j] = (m != 0ull || (seeds && k == 0)) ? 1 : 0;
+  }
+}
+
 // One launch for every frame size: the frame queue hands out frames, the register budget (tiles per wave) is
 // chosen per frame.  Frames with more than TL_NTMAX tile rows are skipped (caller's fallback kernel).
 extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max) {
@@ -648,7 +653,7 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
   return (2 * Npad * nmax + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.work_counter (6 ints) / A.debug are set by the caller (eaqhm_ls_batch).
+// A.scratch / A.scratch_stride / A.gapflag / A.work_counter (6 ints) / A.debug are set by the caller (eaqhm_ls_batch).
 // Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int Kcmax = A.Kcmax;
@@ -656,6 +661,10 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int TS = 32;
   const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+  if (A.mode == 1) {
+    hipLaunchKernelGGL(eaqhm_ls_gapflag_kernel, dim3(A.n_frames), dim3(256), 0, ctx->stream, A, (unsigned char*)A.gapflag);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(eaqhm_ls_tile_kernel, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max);
   HIP_TRY(ctx, hipGetLastError());
