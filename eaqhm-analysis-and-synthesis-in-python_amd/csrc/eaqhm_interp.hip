@@ -193,50 +193,79 @@ __device__ inline double unwrap_diff(double dd) {
   return m;
 }
 
-// phase_integr_interpolation (functions.py:537-575) on one knot interval; returns the integrated and
-// corrected phase at offsets ra and rb (0 <= ra, rb <= D)
-__device__ inline void integrate_interval(const FmPiece& P, double phi0, double phi1, int D, double fs,
-                                          const double* ft, int ra, int rb, double& pa, double& pb) {
-  const double scale = 2.0 * M_PI / fs;
-  double w0 = scale * P(0);
-  double acc = w0, sa = w0, sb = w0;
-  for (int u = 1; u <= D; ++u) {
-    acc += scale * P(u);
-    if (u == ra) sa = acc;
-    if (u == rb) sb = acc;
-  }
-  const double shift = phi0 - w0;
-  const double pend = acc + shift;
-  const double e = pend - phi1;
-  const double Mr = rint(e / (2.0 * M_PI));
-  const double er = M_PI * (e - 2.0 * M_PI * Mr) / (2.0 * (double)D);
-  double c = 0.0, ca = 0.0, cb = 0.0;
-  for (int u = 0; u <= D; ++u) {
-    c += ft[u] * er;
-    if (u == ra) ca = c;
-    if (u == rb) cb = c;
-  }
-  pa = (sa + shift) - ca;
-  pb = (sb + shift) - cb;
-}
-
-extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A) {
+// Block of TBS consecutive samples x all slots, two stages.
+//   stage 1  one thread per (knot interval, slot) touching the block: phase_integr_interpolation
+//            (functions.py:537-575) of the whole interval ONCE, in the reference's summation order — cumulative
+//            sum of the instantaneous frequency, shifted to start at the analysed phase, minus the cumulative
+//            sine bump that closes the phase error at the next knot.  The values at the block's samples go to
+//            LDS:  X1[k][s] phase at sample s, X2[k][s] phase one sample earlier (same interval),
+//            X3[k][knot] fm_recon at the first sample of the interval that starts at the knot.
+//   stage 2  one thread per (sample, slot group): amplitudes, next-iteration frequency from the unwrapped phase
+//            (functions.py:375), knot bookkeeping, am*cos(ph) into LDS; then one thread per sample adds the
+//            slots in slot order, the a0 spline and the reconstruction error (functions.py:385-388).
+extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, int TBS, int NK) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* ft = lds;                 // step+1
-  double* red = lds + A.step + 1;   // 2*4
-  const int D = A.step;
-  for (int u = threadIdx.x; u <= D; u += blockDim.x) ft[u] = sin(M_PI * (double)u / (double)D);
+  const int D = A.step, K = A.Kmax;
+  double* ft = lds;                           // D+1
+  double* X1 = lds + ((D + 1 + 1) & ~1);      // [K][TBS]
+  double* X2 = X1 + (size_t)K * TBS;          // [K][TBS]
+  double* X3 = X2 + (size_t)K * TBS;          // [K][NK]
+  const int tid = threadIdx.x;
+  for (int u = tid; u <= D; u += blockDim.x) ft[u] = sin(M_PI * (double)u / (double)D);
   __syncthreads();
-  const long long t = A.t_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t0 = A.t_lo + (long long)blockIdx.x * TBS;
+  const long long t1 = (t0 + TBS < A.t_hi) ? (t0 + TBS) : A.t_hi;      // block covers [t0, t1)
+  const long long tk0 = ((t0 + D - 1) / D) * D;                        // first knot at or after t0
+  // ---- stage 1: intervals (j, j+1) whose samples j*D .. (j+1)*D meet the block
+  {
+    const int jlo = (int)((t0 > 0) ? ((t0 - 1) / D) : 0), jhi = (int)((t1 - 1) / D);
+    const int nint = jhi - jlo + 1;
+    const double scale = 2.0 * M_PI / A.fs;
+    for (int p = tid; p < nint * K; p += blockDim.x) {
+      const int jj = p / K, k = p - jj * K, j = jlo + jj;
+      if (j + 1 >= A.No_ti) continue;
+      Slot S{A, k};
+      const int cj = S.code(j);
+      if (cj == 0 || S.code(j + 1) == 0) continue;
+      const FmPiece P = make_piece(S, j, cj);
+      const double p0 = P(0), w0 = scale * p0;
+      double acc = w0;
+      for (int u = 1; u <= D; ++u) acc += scale * P(u);
+      const double shift = S.ph(j) - w0;
+      const double e = (acc + shift) - S.ph(j + 1);
+      const double Mr = rint(e / (2.0 * M_PI));
+      const double er = M_PI * (e - 2.0 * M_PI * Mr) / (2.0 * (double)D);
+      const long long tb = (long long)j * D;
+      if (tb >= t0 && tb < t1) X3[(size_t)k * NK + (int)((tb - tk0) / D)] = p0;
+      acc = w0;
+      double c = ft[0] * er;
+      double prev = (acc + shift) - c;
+      for (int u = 1; u <= D; ++u) {
+        acc += scale * P(u);
+        c += ft[u] * er;
+        const double ph = (acc + shift) - c;
+        const long long t = tb + u;
+        if (t >= t0 && t < t1) {
+          X1[(size_t)k * TBS + (int)(t - t0)] = ph;
+          X2[(size_t)k * TBS + (int)(t - t0)] = prev;
+        }
+        prev = ph;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stage 2
+  const int s = tid % TBS, g = tid / TBS, G = blockDim.x / TBS;
+  const long long t = t0 + s;
   const bool live = t < A.t_hi;
-  double dsum = 0.0, dsq = 0.0;
+  int i = 0, r = 0;
+  bool past = false;
   if (live) {
-    int i = (int)(t / D);
-    int r = (int)(t - (long long)i * D);
+    i = (int)(t / D);
+    r = (int)(t - (long long)i * D);
     if (i >= A.No_ti) { i = A.No_ti - 1; r = (int)(t - (long long)i * D); }  // beyond the last instant
-    const bool past = (i == A.No_ti - 1) && (r > 0);
-    double synth = 0.0;
-    for (int k = 0; k < A.Kmax; ++k) {
+    past = (i == A.No_ti - 1) && (r > 0);
+    for (int k = g; k < K; k += G) {
       Slot S{A, k};
       double amv = 0.0, phv = 0.0, fnext = 0.0;
       const int ci = S.code(i);
@@ -246,51 +275,52 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A) 
           const double x0 = (double)i * (double)D, x1 = (double)(i + 1) * (double)D;
           const double a0v = S.am(i), a1v = S.am(i + 1);
           amv = ((a1v - a0v) / (x1 - x0)) * ((double)t - x0) + a0v;
-          FmPiece P = make_piece(S, i, ci);
-          double pr, pm;
-          integrate_interval(P, S.ph(i), S.ph(i + 1), D, A.fs, ft, r, r - 1, pr, pm);
+          const double pr = X1[(size_t)k * TBS + s], pm = X2[(size_t)k * TBS + s];
           phv = pr;
           fnext = A.fs / (2.0 * M_PI) * unwrap_diff(pr - pm);
         }
-      } else if (!past || r == 0) {
-        if (r == 0 && ci != 0) {  // on a knot
+      } else if (r == 0) {
+        if (ci != 0) {  // on a knot
           amv = S.am(i);
           const bool prev = S.code(i - 1) != 0, next = S.code(i + 1) != 0;
           if (!prev && !next) {
             phv = S.ph(i);  // isolated accepted instant: frame-centre values stay as written
           } else {
             double pD = 0.0, pDm1 = 0.0;
-            if (prev) {
-              FmPiece Pp = make_piece(S, i - 1, S.code(i - 1));
-              integrate_interval(Pp, S.ph(i - 1), S.ph(i), D, A.fs, ft, D, D - 1, pD, pDm1);
-            }
+            if (prev) { pD = X1[(size_t)k * TBS + s]; pDm1 = X2[(size_t)k * TBS + s]; }
             if (next) {
-              FmPiece P = make_piece(S, i, ci);
-              double w0 = (2.0 * M_PI / A.fs) * P(0);
+              const double p0 = X3[(size_t)k * NK + (int)((t - tk0) / D)];
+              const double w0 = (2.0 * M_PI / A.fs) * p0;
               phv = w0 + (S.ph(i) - w0);  // first sample of the next interval overwrites the knot
-              if (!prev) fnext = P(0);    // first sample of the run keeps fm_recon (functions.py:375)
+              if (!prev) fnext = p0;      // first sample of the run keeps fm_recon (functions.py:375)
             } else {
               phv = pD;                   // last knot of a run keeps the integrated phase
             }
             if (prev) fnext = A.fs / (2.0 * M_PI) * unwrap_diff(phv - pDm1);
           }
-          A.ph_knot[(size_t)i * A.Kmax + k] = phv;
-        } else if (r == 0) {
-          A.ph_knot[(size_t)i * A.Kmax + k] = 0.0;
+          A.ph_knot[(size_t)i * K + k] = phv;
+        } else {
+          A.ph_knot[(size_t)i * K + k] = 0.0;
         }
       }
       A.am_out[(size_t)k * A.L + t] = amv;
       A.fm_out[(size_t)k * A.L + t] = fnext;
-      if (amv != 0.0) synth += amv * cos(phv);
+      X1[(size_t)k * TBS + s] = (amv != 0.0) ? amv * cos(phv) : 0.0;   // same thread read this cell above
     }
+  }
+  __syncthreads();
+  double dsum = 0.0, dsq = 0.0;
+  if (tid < TBS && live) {
+    double synth = 0.0;
+    for (int k = 0; k < K; ++k) synth += X1[(size_t)k * TBS + s];
     // a0: not-a-knot spline through every instant, extrapolated past the last one (functions.py:340)
     int ia = i;
     if (ia > A.No_ti - 2) ia = A.No_ti - 2;
-    const int ld = A.Kmax + 1;
-    const size_t RS = 3 * (size_t)A.Kmax + 1;
+    const int ld = K + 1;
+    const size_t RS = 3 * (size_t)K + 1;
     double a0v = spline_piece(A.records[(size_t)ia * RS + RS - 1], A.records[(size_t)(ia + 1) * RS + RS - 1],
-                              A.mom[(size_t)ia * ld + A.Kmax],
-                              A.mom[(size_t)(ia + 1) * ld + A.Kmax], (double)(t - (long long)ia * D), (double)D);
+                              A.mom[(size_t)ia * ld + K],
+                              A.mom[(size_t)(ia + 1) * ld + K], (double)(t - (long long)ia * D), (double)D);
     const double sh = a0v + 2.0 * synth;
     A.s_hat[t] = sh;
     if (t >= A.s_lo && t < A.s_hi) {
@@ -298,28 +328,32 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A) 
       dsum = d; dsq = d * d;
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    dsum += __shfl_xor(dsum, o);
-    dsq += __shfl_xor(dsq, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    red[2 * (threadIdx.x >> 6)] = dsum;
-    red[2 * (threadIdx.x >> 6) + 1] = dsq;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
-    A.partials[2 * (size_t)blockIdx.x] = a;
-    A.partials[2 * (size_t)blockIdx.x + 1] = b;
+  if (tid < 64) {   // TBS <= 64: the block's samples sit in the first wave
+    for (int o = 32; o > 0; o >>= 1) {
+      dsum += __shfl_xor(dsum, o);
+      dsq += __shfl_xor(dsq, o);
+    }
+    if (tid == 0) {
+      A.partials[2 * (size_t)blockIdx.x] = dsum;
+      A.partials[2 * (size_t)blockIdx.x + 1] = dsq;
+    }
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double* partials, long long nblocks, double n,
-                                                                    double std_det, double* sums_out) {
+// partials of `group` consecutive blocks are added first, so that the result does not depend on the block size
+extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double* partials, long long nblocks, int group,
+                                                                    double n, double std_det, double* sums_out) {
   __shared__ double red[8];
   double a = 0, b = 0;
-  for (long long q = threadIdx.x; q < nblocks; q += blockDim.x) { a += partials[2 * q]; b += partials[2 * q + 1]; }
+  const long long ngroups = (nblocks + group - 1) / group;
+  for (long long q = threadIdx.x; q < ngroups; q += blockDim.x) {
+    double pa = 0, pb = 0;
+    for (int w = 0; w < group; ++w) {
+      const long long x = q * group + w;
+      if (x < nblocks) { pa += partials[2 * x]; pb += partials[2 * x + 1]; }
+    }
+    a += pa; b += pb;
+  }
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
   if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
   __syncthreads();
@@ -385,10 +419,23 @@ extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t
   return EAQHM_OK;
 }
 
+// samples per block of eaqhm_eval_kernel: the largest of 64/32/16 whose LDS tables fit
+static int eval_block_samples(int Kmax, int step, size_t* lds_bytes, int* nk) {
+  for (int tbs = 64; tbs >= 16; tbs >>= 1) {
+    const int NK = tbs / step + 2;
+    const size_t bytes = (((size_t)step + 2) & ~(size_t)1) * 8 + ((size_t)2 * Kmax * tbs + (size_t)Kmax * NK) * 8;
+    if (bytes <= 72 * 1024 || tbs == 16) {
+      *lds_bytes = bytes; *nk = NK;
+      return tbs;
+    }
+  }
+  return 16;
+}
+
 extern "C" int64_t eaqhm_eval_partials_len(int64_t t_lo, int64_t t_hi, int32_t step) {
   (void)step;
   if (t_hi <= t_lo) return 2;
-  return 2 * ((t_hi - t_lo + 255) / 256);
+  return 2 * ((t_hi - t_lo + 15) / 16);   // one pair per block of >= 16 samples
 }
 
 extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uint8_t* code,
@@ -403,12 +450,16 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   if ((int64_t)(No_ti - 1) * step >= L) return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: instants beyond the signal");
   EvalArgs A{records, code, mom, No_ti, Kmax, step, fs, (long long)L, (long long)t_lo, (long long)t_hi,
              (long long)s_lo, (long long)s_hi, target, am_out, fm_out, ph_knot, s_hat, partials};
-  const long long nblocks = (t_hi - t_lo + 255) / 256;
-  size_t lds_bytes = ((size_t)step + 1 + 8) * sizeof(double);
-  hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A);
+  size_t lds_bytes = 0;
+  int NK = 0;
+  const int TBS = eval_block_samples(Kmax, step, &lds_bytes, &NK);
+  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: Kmax too large for the LDS tables");
+  const long long nblocks = (t_hi - t_lo + TBS - 1) / TBS;
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, (double)(s_hi - s_lo),
-                     std_det, sums_out);
+  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, 256 / TBS,
+                     (double)(s_hi - s_lo), std_det, sums_out);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

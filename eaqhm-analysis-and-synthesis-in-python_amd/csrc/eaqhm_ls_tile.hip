@@ -307,13 +307,15 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     STAMP(0);
 
     // system tiles of this wave (compute waves only)
-    d4 accR[NS], accI[NS];
+    constexpr bool M3 = (NS <= 5);   // register budget: a third accumulator per tile only for the smaller frames
+    d4 accR[NS], accI[NS], acc3[M3 ? NS : 1];
     int tP[NS], tQ[NS];
     bool live[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
       accR[sl] = (d4){0, 0, 0, 0};
       accI[sl] = (d4){0, 0, 0, 0};
+      if (M3) acc3[sl] = (d4){0, 0, 0, 0};
       const int x = sl * TL_CW + wave;
       live[sl] = (!spec) && (x < ntiles);
       int P = 0, Q = 0;
@@ -428,14 +430,28 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
           const int sw = (lcol + (row >> 1)) & 15;
           const int oa = row * ldx + ca + sw, ob = row * ldx + cb + sw;
           const double aR = Xre[oa], aI = Xim[oa], bR = Xre[ob], bI = Xim[ob];
-          accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
-          accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
-          accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
-          accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
+          if constexpr (M3) {   // three real products per complex one: P1 = aR bR, P2 = aI bI, P3 = (aR+aI)(bI-bR)
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
+            acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI - bR, accI[sl], 0, 0, 0);
+          } else {
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
+          }
         }
       }
       __syncthreads();
       STAMP(2);
+    }
+    if constexpr (M3) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        const d4 p1 = accR[sl], p2 = acc3[sl];
+        accR[sl] = p1 + p2;
+        accI[sl] = accI[sl] + (p1 - p2);
+      }
     }
 
     {
@@ -628,7 +644,8 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
     const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
     if (nt <= 8) tile_frame<5>(A, TS, ldx_max, lds, f);         // <= 36 tiles
-    else if (nt <= 10) tile_frame<7>(A, TS, ldx_max, lds, f);   // 45 / 55 tiles
+    else if (nt == 9) tile_frame<6>(A, TS, ldx_max, lds, f);    // 45 tiles
+    else if (nt == 10) tile_frame<7>(A, TS, ldx_max, lds, f);   // 55 tiles
     else if (nt == 11) tile_frame<9>(A, TS, ldx_max, lds, f);   // 66 tiles
     else if (nt <= TL_NTMAX) tile_frame<12>(A, TS, ldx_max, lds, f);  // 78 / 91 tiles
   }

@@ -12,7 +12,7 @@ eng.run()
 eng.reset(); 
 d = eng.ctx.debug_read()
 names = ["setup+A1", "build: barrier wait", "contraction", "(fact tail)", "backsubst", "record", "publish diag", "trsm", "update", "-", "diag_coop", "build: items (thread 0)", "build: rows (thread 0)"]
-tot = sum(d[:6])
+tot = sum(d[:13])
 for n, v in zip(names, d):
     print("%-20s %12d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
 print("frames", eng.n_ls_frames, "cycles/frame", tot / max(1, 6 * 4169))
