@@ -309,9 +309,12 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
     const size_t st_m = ls_mfma_scratch_stride(nmax, Nmax, Kcmax), st_t = ls_tile_scratch_stride(nmax, Nmax);
     const size_t frame_bytes = (st_m > st_t ? st_m : st_t) * grid * sizeof(double);
     const size_t flag_bytes = (((size_t)n_frames * Kmax) + 255) & ~(size_t)255;
-    int rc = ctx->reserve(frame_bytes + flag_bytes + 256);
+    const size_t cls_bytes = ((16 + (size_t)6 * n_frames) * sizeof(int) + 255) & ~(size_t)255;
+    int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
     if (rc) return rc;
     B.gapflag = (const unsigned char*)ctx->scratch + frame_bytes;
+    B.cls = (int*)((char*)ctx->scratch + frame_bytes + flag_bytes);
+    HIP_TRY(ctx, hipMemsetAsync(B.cls, 0, 16 * sizeof(int), ctx->stream));
     int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
     B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
@@ -338,7 +341,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
   A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
   A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
-  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr; A.gapflag = nullptr;
+  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr; A.gapflag = nullptr; A.cls = nullptr;
   size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

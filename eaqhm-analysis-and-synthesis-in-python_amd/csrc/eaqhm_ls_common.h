@@ -18,6 +18,9 @@ struct LsArgs {
   double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
   int* work_counter;  // dynamic frame queue; may be null
   const unsigned char* gapflag;  // [n_frames][Kmax] window-has-a-zero flags (tile variant, mode 1)
+  // frames bucketed by size (tile variant): cls[0..5] counts, cls[8..13] cursors, cls[16 + c*n_frames + i] frame ids.
+  // Classes 0-4 are the register budgets of eaqhm_ls_tile_kernel, class 5 is left to eaqhm_ls_mfma_kernel.
+  int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
 };
 

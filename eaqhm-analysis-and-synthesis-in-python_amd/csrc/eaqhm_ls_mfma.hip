@@ -46,6 +46,7 @@ __device__ inline void tile_of(int q, int& I, int& J) {
 
 extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int TS, int ldx_max, int min_nb) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (min_nb > 0 && A.cls[5] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
   const int tid = threadIdx.x, nt = MF_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the unit bookkeeping in SGPRs
@@ -70,18 +71,20 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
   __syncthreads();
   const int PE = TS / 2;  // sample pairs per chunk
 
+  // after eaqhm_ls_tile_kernel (min_nb > 0) only the frames of size class 5 are left, usually none
+  const int n_items = (min_nb > 0) ? A.cls[5] : A.n_frames;
   for (;;) {
-    if (tid == 0) shi[0] = atomicAdd(A.work_counter, 1);
+    if (tid == 0) shi[0] = atomicAdd((min_nb > 0) ? (A.cls + 8 + 5) : A.work_counter, 1);
     __syncthreads();
-    const int f = shi[0];
+    const int item = shi[0];
     __syncthreads();
-    if (f >= A.n_frames) break;
+    if (item >= n_items) break;
+    const int f = (min_nb > 0) ? A.cls[16 + (size_t)5 * A.n_frames + item] : item;
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
     const int N = 2 * wl + 1, mid = wl;
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
     const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc, ldl = M + 1;
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
-    if (min_nb > 0 && (2 * Kc + 1 + 15) / 16 <= 13) continue;  // done by eaqhm_ls_tile_kernel (<= 13 tile rows)
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
     const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
     const int npass = (units + MF_WAVES * MF_NSLOT - 1) / (MF_WAVES * MF_NSLOT);

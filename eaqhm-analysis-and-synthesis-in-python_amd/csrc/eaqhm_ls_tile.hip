@@ -235,6 +235,8 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
   __syncthreads();
 }
 
+// One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
+// the five budgets into one kernel body spills several hundred VGPRs).
 template <int NS>
 __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, int ldx_max, double* lds, int f) {
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
@@ -613,6 +615,18 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   }
 }
 
+// Frames bucketed by the number of tile rows of their system (see LsArgs::cls).
+__device__ inline int frame_class(int n) {
+  const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
+  return nt <= 8 ? 0 : nt == 9 ? 1 : nt == 10 ? 2 : nt == 11 ? 3 : nt <= TL_NTMAX ? 4 : 5;
+}
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArgs A) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= A.n_frames) return;
+  const int cl = frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
+  A.cls[16 + (size_t)cl * A.n_frames + atomicAdd(A.cls + cl, 1)] = f;
+}
+
 // Which (frame, slot) windows contain a zero of the frequency track: one wave per slot, whole chip busy, so the
 // persistent kernel below never has to scan windows that need no bridging (the common case).
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_gapflag_kernel(LsArgs A, unsigned char* flags) {
@@ -630,25 +644,26 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_gapflag_kernel(LsArgs
   }
 }
 
-// One launch for every frame size: the frame queue hands out frames, the register budget (tiles per wave) is
-// chosen per frame.  Frames with more than TL_NTMAX tile rows are skipped (caller's fallback kernel).
+// One persistent launch for every frame size: each workgroup works through the size classes, largest first, with
+// the register budget (tiles per wave) of the class.
 extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(LsArgs A, int TS, int ldx_max) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ int next_frame;
-  for (;;) {
-    if (threadIdx.x == 0) next_frame = atomicAdd(A.work_counter, 1);
-    __syncthreads();
-    const int f = next_frame;
-    __syncthreads();
-    if (f >= A.n_frames) break;
-    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
-    const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
-    if (nt <= 8) tile_frame<5>(A, TS, ldx_max, lds, f);         // <= 36 tiles
-    else if (nt == 9) tile_frame<6>(A, TS, ldx_max, lds, f);    // 45 tiles
-    else if (nt == 10) tile_frame<7>(A, TS, ldx_max, lds, f);   // 55 tiles
-    else if (nt == 11) tile_frame<9>(A, TS, ldx_max, lds, f);   // 66 tiles
-    else if (nt <= TL_NTMAX) tile_frame<12>(A, TS, ldx_max, lds, f);  // 78 / 91 tiles
+  __shared__ int nxt;
+#define RUN_CLASS(NSV, C)                                                                \
+  for (;;) {                                                                             \
+    if (threadIdx.x == 0) nxt = atomicAdd(A.cls + 8 + C, 1);                             \
+    __syncthreads();                                                                     \
+    const int item = nxt;                                                                \
+    __syncthreads();                                                                     \
+    if (item >= A.cls[C]) break;                                                         \
+    tile_frame<NSV>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);     \
   }
+  RUN_CLASS(12, 4)   // 78 / 91 tiles
+  RUN_CLASS(9, 3)    // 66 tiles
+  RUN_CLASS(7, 2)    // 55 tiles
+  RUN_CLASS(6, 1)    // 45 tiles
+  RUN_CLASS(5, 0)    // <= 36 tiles
+#undef RUN_CLASS
 }
 
 static size_t tl_usize_c() {
@@ -670,7 +685,7 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
   return (2 * Npad * nmax + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.gapflag / A.work_counter (6 ints) / A.debug are set by the caller (eaqhm_ls_batch).
+// A.scratch / A.scratch_stride / A.gapflag / A.cls (zeroed header) / A.debug are set by the caller (eaqhm_ls_batch).
 // Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int Kcmax = A.Kcmax;
@@ -678,6 +693,8 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int TS = 32;
   const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+  hipLaunchKernelGGL(eaqhm_ls_classify_kernel, dim3((A.n_frames + 255) / 256), dim3(256), 0, ctx->stream, A);
+  HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
     hipLaunchKernelGGL(eaqhm_ls_gapflag_kernel, dim3(A.n_frames), dim3(256), 0, ctx->stream, A, (unsigned char*)A.gapflag);
     HIP_TRY(ctx, hipGetLastError());
