@@ -92,9 +92,15 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const doub
   double M = 0.0;
   unsigned char cd = 0;
   if (C.acc(i)) {
-    int dl = 0, dr = 0;
-    while (dl < SPL_CAP && C.acc(i - dl - 1)) ++dl;
-    while (dr < SPL_CAP && C.acc(i + dr + 1)) ++dr;
+    // accepted neighbours on both sides as bit masks (independent loads, no dependent chain), then the run
+    // lengths are the trailing ones of the masks
+    unsigned long long ml = 0ull, mr = 0ull;
+#pragma unroll 8
+    for (int d = 0; d < SPL_CAP; ++d) {
+      if (C.acc(i - d - 1)) ml |= 1ull << d;
+      if (C.acc(i + d + 1)) mr |= 1ull << d;
+    }
+    const int dl = min(SPL_CAP, __ffsll((long long)~ml) - 1), dr = min(SPL_CAP, __ffsll((long long)~mr) - 1);
     const bool kl = dl < SPL_CAP, kr = dr < SPL_CAP;
     const int m = dl + dr + 1;
     if (kl && kr && m < 4) {

@@ -17,7 +17,9 @@ struct LsArgs {
   double* records; double* raw_amp; double* raw_slope;
   double* scratch; size_t scratch_stride; int nmax; int Nmax; int Kcmax;
   int* work_counter;  // dynamic frame queue; may be null
-  const unsigned char* gapflag;  // [n_frames][Kmax] window-has-a-zero flags (tile variant, mode 1)
+  // zero counts of the frequency tracks (tile variant, mode 1; eaqhm_ls_zero_prefix_kernel): zloc[k][t] = zeros of
+  // fm_cur[k] from the start of t's 1024-sample chunk up to t, ztot[k][chunk] = zeros of the whole chunk
+  const unsigned short* zloc; const int* ztot; int zchunks;
   // frames bucketed by size (tile variant): cls[0..5] counts, cls[8..13] cursors, cls[16 + c*n_frames + i] frame ids.
   // Classes 0-4 are the register budgets of eaqhm_ls_tile_kernel, class 5 is left to eaqhm_ls_mfma_kernel.
   int* cls;

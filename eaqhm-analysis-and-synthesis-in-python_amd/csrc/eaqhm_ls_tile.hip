@@ -48,7 +48,7 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   Q = x - P * (P + 1) / 2;
 }
 // ---- Phase A1 -----------------------------------------------------------------------------------------------
-// Per-slot set-up.  A slot whose track has no zero inside the frame's window (flag from eaqhm_ls_gapflag_kernel;
+// Per-slot set-up.  A slot whose track has no zero inside the frame's window (two look-ups in the zero counts;
 // the common case) needs nothing but its centre values: the basis build reads the track itself and integrates
 // the frequency on the fly, outwards from the centre.  A slot with gaps gets its window bridged
 // (functions.py:251-278) into the workgroup's scratch rows, which the build then reads instead of the track.
@@ -69,12 +69,19 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
   };
   int anyg = 0;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const int g = A.gapflag[(size_t)f * A.Kmax + j];
+    // zeros of the track inside [c-wl, c+wl] (the window is shorter than a chunk: at most two chunks involved);
+    // a seeded slot 0 (functions.py:209-210) shows substituted values: route it through the bridged copy too
+    const int k = mycols[j];
+    const long long b = (long long)c + wl, a1 = (long long)c - wl - 1;
+    const int cb = (int)(b >> 10), ca = (a1 >= 0) ? (int)(a1 >> 10) : 0;
+    int zc = A.zloc[(size_t)k * A.L + b] + ((cb != ca) ? A.ztot[(size_t)k * A.zchunks + ca] : 0);
+    if (a1 >= 0) zc -= A.zloc[(size_t)k * A.L + a1];
+    const int g = (zc != 0 || (seeds && k == 0)) ? 1 : 0;
     gappy[j] = g;
     anyg |= g;
     ci[j * CI_STRIDE + 0] = 0.0;
     ci[j * CI_STRIDE + 1] = 0.0;
-    if (!g) centre(j, track_fm(A, mycols[j], c, c, seeds), track_am(A, mycols[j], c, c, seeds));
+    if (!g) centre(j, track_fm(A, k, c, c, seeds), track_am(A, k, c, c, seeds));
   }
   if (!__syncthreads_or(anyg)) return;
   // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
@@ -621,27 +628,42 @@ __device__ inline int frame_class(int n) {
   return nt <= 8 ? 0 : nt == 9 ? 1 : nt == 10 ? 2 : nt == 11 ? 3 : nt <= TL_NTMAX ? 4 : 5;
 }
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArgs A) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= A.n_frames) return;
-  const int cl = frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
-  A.cls[16 + (size_t)cl * A.n_frames + atomicAdd(A.cls + cl, 1)] = f;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const int cl = (f < A.n_frames) ? frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]) : -1;
+  for (int c = 0; c < 6; ++c) {   // one atomic per wave and class, positions from the ballot
+    const unsigned long long m = __ballot(cl == c);
+    if (m == 0ull) continue;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(A.cls + c, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (cl == c) A.cls[16 + (size_t)c * A.n_frames + base + __popcll(m & ((1ull << lane) - 1ull))] = f;
+  }
 }
 
-// Which (frame, slot) windows contain a zero of the frequency track: one wave per slot, whole chip busy, so the
-// persistent kernel below never has to scan windows that need no bridging (the common case).
-extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_gapflag_kernel(LsArgs A, unsigned char* flags) {
-  const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = A.ncol[f], c = A.frame_c[f], wl = A.frame_wl[f], N = 2 * wl + 1;
-  const bool seeds = A.any_seed && (*A.any_seed != 0);
-  const long long t0 = (long long)c - wl;
-  for (int j = wave; j < n; j += 4) {
-    const int k = A.cols[(size_t)f * A.Kmax + j];
-    bool z = false;
-    for (int t = lane; t < N; t += 64) z |= (track_fm(A, k, t0 + t, c, seeds) == 0.0);
+// Zero counts of every frequency track, in chunks of 1024 samples (LsArgs::zloc / ztot): a frame then knows with two
+// look-ups per slot whether its window needs bridging, instead of scanning n windows of N samples.
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(const double* __restrict__ fm, long long L,
+                                                                              int zchunks, unsigned short* __restrict__ zloc,
+                                                                              int* __restrict__ ztot) {
+  __shared__ int wsum[4];
+  const int k = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long base = (long long)ch << 10;
+  int run = 0;
+  for (int p = 0; p < 4; ++p) {
+    const long long t = base + 256 * p + tid;
+    const bool z = (t < L) && (fm[(size_t)k * L + t] == 0.0);
     const unsigned long long m = __ballot(z);
-    // a seeded slot 0 (functions.py:209-210) shows substituted values: route it through the bridged copy too
-    if (lane == 0) flags[(size_t)f * A.Kmax + j] = (m != 0ull || (seeds && k == 0)) ? 1 : 0;
+    const int incl = __popcll(m & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int v = wsum[w]; tot += v; if (w < wave) off += v; }
+    if (t < L) zloc[(size_t)k * L + t] = (unsigned short)(run + off + incl);
+    run += tot;
+    __syncthreads();
   }
+  if (tid == 0) ztot[(size_t)k * zchunks + ch] = run;
 }
 
 // One persistent launch for every frame size: each workgroup works through the size classes, largest first, with
@@ -685,7 +707,7 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
   return (2 * Npad * nmax + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.gapflag / A.cls (zeroed header) / A.debug are set by the caller (eaqhm_ls_batch).
+// A.scratch / A.scratch_stride / A.zloc / A.ztot / A.cls (zeroed header) / A.debug are set by the caller (eaqhm_ls_batch).
 // Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int Kcmax = A.Kcmax;
@@ -696,7 +718,8 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   hipLaunchKernelGGL(eaqhm_ls_classify_kernel, dim3((A.n_frames + 255) / 256), dim3(256), 0, ctx->stream, A);
   HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
-    hipLaunchKernelGGL(eaqhm_ls_gapflag_kernel, dim3(A.n_frames), dim3(256), 0, ctx->stream, A, (unsigned char*)A.gapflag);
+    hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(A.zchunks, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.L,
+                       A.zchunks, (unsigned short*)A.zloc, (int*)A.ztot);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
