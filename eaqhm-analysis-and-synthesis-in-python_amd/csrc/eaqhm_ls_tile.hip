@@ -433,22 +433,37 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       for (int sl = 0; sl < NS; ++sl) {
         if (!live[sl]) continue;
         const int ca = 16 * tP[sl], cb = 16 * tQ[sl];
-#pragma clang loop unroll(disable)
-        for (int ks = 0; ks < TS / 4; ++ks) {
-          const int row = 4 * ks + lq;
-          const int sw = (lcol + (row >> 1)) & 15;
-          const int oa = row * ldx + ca + sw, ob = row * ldx + cb + sw;
-          const double aR = Xre[oa], aI = Xim[oa], bR = Xre[ob], bI = Xim[ob];
+        // operands of k-step ks+1 are requested before the MFMAs of k-step ks are issued (LDS latency hidden
+        // behind the matrix pipe); row = 4 ks + lq, column swizzle (lcol + row/2) & 15
+        int rb = lq * ldx;
+        const int sw0 = lcol + (lq >> 1);
+        asm volatile("" : "+v"(rb));   // keep the address arithmetic inside the loop (hoisted, it spills)
+        const int plane = TS * ldx_max;
+        double aR, aI, bR, bI;
+        {
+          const int sw = sw0 & 15;
+          aR = Xre[rb + ca + sw]; aI = Xre[rb + ca + sw + plane]; bR = Xre[rb + cb + sw]; bI = Xre[rb + cb + sw + plane];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {   // TS = 32 rows
+          double naR = 0, naI = 0, nbR = 0, nbI = 0;
+          if (ks < 7) {
+            rb += 4 * ldx;
+            const int sw = (sw0 + 2 * (ks + 1)) & 15;
+            naR = Xre[rb + ca + sw]; naI = Xre[rb + ca + sw + plane]; nbR = Xre[rb + cb + sw]; nbI = Xre[rb + cb + sw + plane];
+          }
+          __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs below
           if constexpr (M3) {   // three real products per complex one: P1 = aR bR, P2 = aI bI, P3 = (aR+aI)(bI-bR)
             accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
             acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl], 0, 0, 0);
             accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI - bR, accI[sl], 0, 0, 0);
           } else {
             accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
-            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
             accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
+            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
             accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
           }
+          aR = naR; aI = naI; bR = nbR; bI = nbI;
         }
       }
       __syncthreads();
