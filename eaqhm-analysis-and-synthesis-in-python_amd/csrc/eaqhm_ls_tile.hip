@@ -1,9 +1,8 @@
 // eaqhm_ls_tile.hip — the per-frame LS entirely on chip: Gramian AND factorisation on the FP64 matrix cores,
 // the system matrix never leaves the register file (gfx950).
 //
-// A workgroup of 512 threads owns one frame at a time (atomic frame queue): 7 compute waves that own the
-// system tiles in their registers, and 1 specialist wave that factorises the diagonal tiles (its register
-// file is free of accumulators, so the serial 16-column chain runs without spills).
+// A workgroup of 512 threads (8 waves, every wave owns system tiles in its registers) works on one frame at a
+// time; frames are bucketed by size on the device and handed out by per-class atomic cursors, largest first.
 //
 // Stacked basis.  With Y[t] = w_t * [ E2(t) | n_t E2(t) | s_t ]  (2Kc+1 columns; E2 = [negative | DC | positive]
 // columns of functions.py:516-519, w the analysis window, n_t = t - mid) the normal equations of
@@ -12,14 +11,15 @@
 // costs nothing.  Every 16x16 complex tile of Y^H Y is one MFMA accumulation over time, owned by one wave
 // (tile x = P(P+1)/2+Q -> wave x%8, slot x/8) from the first sample to the last back-substitution step.
 //
-//   A1     one wave per (slot, 64-sample chunk): coalesced track windows, gaps found with ballots and bridged,
-//          wave scan of fm                                                                  -> global scratch
-//   A3+B   chunks of 16 sample PAIRS (u, N-2-u) built in LDS by all threads — the pair shares its sincos
-//          because the negative-frequency column at u is the time-reversed positive one (functions.py:284-285)
-//          — and contracted with v_mfma_f64_16x16x4_f64 (4 real MFMAs per k-step and tile)
-//   C      right-looking tile Cholesky: diagonal tile -> LDS -> specialist wave factorises AND inverts it,
-//          panel tiles are multiplied by the inverse (MFMA) and published in LDS, trailing tiles are updated
-//          from LDS operands (MFMA).  Three barriers per panel; no global memory traffic.
+//   A1     per-slot set-up: zero-count look-ups decide whether the slot's window has a gap; gap-free slots need
+//          only their centre values, the others are bridged into per-workgroup scratch rows
+//   A3+B   chunks of 16 sample PAIRS (mid-d-1, mid+d), centre outwards, built in LDS by all threads: track values
+//          loaded directly, phase = running sum (16-lane DPP scan + per-slot carry); the pair shares its sincos
+//          because the negative-frequency column at u is the time-reversed positive one (functions.py:284-285);
+//          contracted with v_mfma_f64_16x16x4_f64, LDS operand reads software-pipelined one k-step ahead
+//   C      right-looking tile Cholesky: diagonal tile -> LDS -> factorised AND inverted by the whole workgroup
+//          (one thread per entry, 2x2 block pivots), panel tiles are multiplied by the inverse (MFMA) and
+//          published in LDS, trailing tiles are updated from LDS operands (MFMA); no global memory traffic
 //   C'     back substitution from the L tiles still sitting in the owners' registers; z, x vectors in LDS
 //   D      frequency mismatch, acceptance, record row (eaqhm_ls_common.h)
 //
