@@ -53,6 +53,7 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
 // the frequency on the fly, outwards from the centre.  A slot with gaps gets its window bridged
 // (functions.py:251-278) into the workgroup's scratch rows, which the build then reads instead of the track.
 //   ci[j]: [0] running sum of fm over (mid, mid+d], [1] over [mid-d, mid]  (carried from chunk to chunk),
+//          [2] / [3] pointers to the slot's fm / am window (track or bridged copy),
 //          [17] 1/(am_mid+eps), [18..19] rho = exp(j 2 pi fm_mid / fs)      (functions.py:508-518, :284-285)
 __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, int Npad, double* ci,
                                      unsigned long long* masks, int* gappy, const int* mycols, int n, int N, int mid,
@@ -81,6 +82,10 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
     anyg |= g;
     ci[j * CI_STRIDE + 0] = 0.0;
     ci[j * CI_STRIDE + 1] = 0.0;
+    // where the build reads this slot's window from: the bridged copy or the track itself
+    const size_t trk = (size_t)k * A.L + t0;
+    ((const double**)(ci + j * CI_STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (A.fm_cur + trk);
+    ((const double**)(ci + j * CI_STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (A.am_cur + trk);
     if (!g) centre(j, track_fm(A, k, c, c, seeds), track_am(A, k, c, c, seeds));
   }
   if (!__syncthreads_or(anyg)) return;
@@ -277,6 +282,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
   double* Rs = Qs + (size_t)Npad * A.nmax;                         // Af[j][t]
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
+  const int mode = A.mode;
+  // phases are q * (2 pi / fs) here, (2 pi q) / fs in the reference (functions.py:513, :453): one rounding each way,
+  // <= 2 ulp of the phase apart, and no IEEE division per basis sample
+  const double w1 = 2.0 * M_PI / A.fs;
   const int PE = TS / 2;
   const int lcol = lane & 15, lq = lane >> 4;
   unsigned long long* dbg = A.debug;
@@ -335,7 +344,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     // ================= Gramian =================
     // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid, taken from the centre outwards so that the phase
     // integral of functions.py:508-515 relative to the centre is a running sum
-    const long long t0 = (long long)c - wl;
     for (int d0 = 0; d0 < npairs; d0 += PE) {
       // logical column cc of chunk rows (2*el, 2*el+1) lives at XCOL(cc, el): the 16 lanes that write one column
       // of 16 different pairs hit 16 different banks, and MFMA operand reads stay conflict-free
@@ -346,25 +354,24 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
         const int u = mid - d - 1, v = mid + d;
         double su = 0, cu = 1, sv, cv;
         double pur = 0, pui = 0, nur = 0, nui = 0, pvr, pvi, nvr, nvi;  // positive / negative column values
-        if (A.mode == 1) {
+        if (mode == 1) {
           double* cj = ci + j * CI_STRIDE;
-          const bool gp = gappy[j] != 0;
-          const size_t trk = (size_t)mycols[j] * A.L + t0;
-          const double* fb = gp ? (Qs + (size_t)j * Npad) : (A.fm_cur + trk);   // bridged copy or the track itself
-          const double* ab = gp ? (Rs + (size_t)j * Npad) : (A.am_cur + trk);
+          const double* fb = ((const double**)cj)[2];   // bridged copy or the track itself (prepare_slots)
+          const double* ab = ((const double**)cj)[3];
           // every load of the item up front, indices clamped into the window (results of clamped ones unused)
           const int dc = act ? d : mid;
           const double fu1 = fb[mid - dc], fv = fb[mid + dc];
           const double au = ab[(mid - dc - 1 >= 0) ? (mid - dc - 1) : 0], au1 = ab[mid - dc];
           const double av = ab[mid + dc], av1 = ab[(mid + dc + 1 < N) ? (mid + dc + 1) : (N - 1)];
+          __builtin_amdgcn_sched_barrier(0);   // all six requests in flight before anything waits on one
           // F(v) - F(mid) = sum of fm over (mid, v];  F(u) - F(mid) = -sum over [u+1, mid]
           const double xu = act ? fu1 : 0.0, xv = (act && d >= 1) ? fv : 0.0;
           const double qv = cj[0] + scan16(xv), qu = -(cj[1] + scan16(xu));
           if (el == 15) { cj[0] = qv; cj[1] = -qu; }   // carried to the next chunk (read again after two barriers)
           if (!act) continue;
           const double ainv = cj[17], pr = cj[18], pi = cj[19];
-          sincos_cw((2.0 * M_PI * qu) / A.fs, &su, &cu);
-          sincos_cw((2.0 * M_PI * qv) / A.fs, &sv, &cv);
+          sincos_cw(qu * w1, &su, &cu);
+          sincos_cw(qv * w1, &sv, &cv);
           const double eps = 10e-5;
           // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
           if (u >= 0) {
@@ -379,10 +386,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
           if (!act) continue;
           const double fk = (double)(j + 1) * f0;
           if (u >= 0) {
-            sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
+            sincos_cw(((double)(u - mid) * fk) * w1, &su, &cu);
             pur = cu; pui = su; nur = cu; nui = -su;
           }
-          sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
+          sincos_cw(((double)(v - mid) * fk) * w1, &sv, &cv);
           pvr = cv; pvi = sv; nvr = cv; nvi = -sv;
         }
         double* xr = Xre + (2 * el) * ldx;
