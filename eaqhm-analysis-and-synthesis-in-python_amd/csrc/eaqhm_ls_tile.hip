@@ -531,18 +531,19 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
             ti[lcol * TL_LD + lq + 4 * r] = accI[sl][r];
           }
           __builtin_amdgcn_wave_barrier();
-          d4 xr = (d4){0, 0, 0, 0}, xi = (d4){0, 0, 0, 0};
+          // X = T W^H with three real products per complex one: P1 = re re, P2 = im im, P3 = (re+im)(re'+im')
+          d4 p1 = (d4){0, 0, 0, 0}, p2 = (d4){0, 0, 0, 0}, p3 = (d4){0, 0, 0, 0};
           const double* wr = WtR + jb * TL_TILE;
           const double* wi = WtI + jb * TL_TILE;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const int o = (4 * ks + lq) * TL_LD + lcol;
             const double aR = tr[o], aI = ti[o], bR = wr[o], bI = wi[o];
-            xr = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, xr, 0, 0, 0);
-            xr = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bI, xr, 0, 0, 0);
-            xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, xi, 0, 0, 0);
-            xi = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bR, xi, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, p1, 0, 0, 0);
+            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, p2, 0, 0, 0);
+            p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bR + bI, p3, 0, 0, 0);
           }
+          const d4 xr = p1 - p2, xi = p3 - (p1 + p2);
           accR[sl] = xr; accI[sl] = xi;  // the finished L tile stays here for the back substitution
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -561,15 +562,19 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
           const double* ai = PanI + tP[sl] * TL_TILE;
           const double* br = PanR + tQ[sl] * TL_TILE;
           const double* bi = PanI + tQ[sl] * TL_TILE;
+          // T -= L_P L_Q^H, three real products: P1 = re re', P2 = im im', P3 = (re+im)(im'-re');
+          // Re -= P1 + P2,  Im += P3 + P1 - P2  (P3 accumulates straight into the imaginary part)
+          d4 p1 = (d4){0, 0, 0, 0}, p2 = (d4){0, 0, 0, 0};
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const int o = (4 * ks + lq) * TL_LD + lcol;
             const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];
-            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aR, lR, accR[sl], 0, 0, 0);
-            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lI, accR[sl], 0, 0, 0);
-            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lI, accI[sl], 0, 0, 0);
-            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, lR, accI[sl], 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lR, p1, 0, 0, 0);
+            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, lI, p2, 0, 0, 0);
+            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, lI - lR, accI[sl], 0, 0, 0);
           }
+          accR[sl] = accR[sl] - (p1 + p2);
+          accI[sl] = accI[sl] + (p1 - p2);
         }
         STAMP(8);
         // (barrier A of the next panel orders these LDS reads before the next panel's writes)
