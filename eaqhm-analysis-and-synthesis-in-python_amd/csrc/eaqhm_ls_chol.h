@@ -1,0 +1,270 @@
+// eaqhm_ls_chol.h — 16x16 complex tile pieces shared by the LS kernels (gfx950, FP64).
+#pragma once
+#include "eaqhm_ls_common.h"
+
+namespace eaqhm {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define TL_LD 17        // tile row stride in LDS (doubles): conflict-free transposing stores
+#define TL_TILE (16 * TL_LD)
+
+// ---- diagonal tile: Cholesky factor L and W = L^-1 of a 16x16 Hermitian positive definite tile, by the whole
+// workgroup.  The sixteen column steps are a serial chain on the critical path of the frame, so each step is
+// made as short as possible: one thread per matrix entry (threads 0-255: D, threads 256-511: the inverse by
+// forward elimination on [L | I]), three LDS reads, one reciprocal, one complex multiply-add, one barrier.
+//   D  [16][16] complex (interleaved), row-major, lower triangle used;  Z likewise (starts as identity)
+//   outputs: Wt planes hold (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j];  Ld planes hold L[i][j] at [i*TL_LD + j]
+__device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
+  // 2x2 block pivots: seven elimination steps instead of fifteen.  With P = [[p, conj(q)], [q, r]] the pivot block
+  // of columns (j, j+1) and a = D[i][j..j+1], b = D[k][j..j+1]:   D[i][k] -= a P^-1 b^H   (i >= k >= j+2), and
+  // the rows of the inverse below the block follow the same elimination on [L | I].  Columns / rows inside a
+  // block stay raw until the final scaling, which applies the block's own 2x2 Cholesky factor.
+  const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
+  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
+  __syncthreads();
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < 14; j += 2) {
+    const bool work = (g == 0) ? (k >= j + 2 && i >= k) : (i >= j + 2 && k <= j + 1);
+    if (work) {
+      double p = D[2 * (j * 16 + j)], r = D[2 * ((j + 1) * 16 + j + 1)];
+      const double qr = D[2 * ((j + 1) * 16 + j)], qi = D[2 * ((j + 1) * 16 + j) + 1];
+      p = (p > 0.0) ? p : 1.0;
+      double det = p * r - (qr * qr + qi * qi);
+      det = (det > 0.0) ? det : 1.0;   // only the RHS position of the last tile can get here (residual ~ 0)
+      double dinv = __builtin_amdgcn_rcp(det);
+      dinv = dinv * fma(-det, dinv, 2.0);
+      dinv = dinv * fma(-det, dinv, 2.0);
+      const double a1r = D[2 * (i * 16 + j)], a1i = D[2 * (i * 16 + j) + 1];
+      const double a2r = D[2 * (i * 16 + j + 1)], a2i = D[2 * (i * 16 + j + 1) + 1];
+      // y = P^-1 [x1; x2] * det = [ r x1 - conj(q) x2 ;  -q x1 + p x2 ],  then  out -= (a1 y1 + a2 y2) / det
+      double x1r, x1i, x2r, x2i;
+      if (g == 0) {   // x = b^H components: conj(D[k][j]), conj(D[k][j+1])
+        x1r = D[2 * (k * 16 + j)];     x1i = -D[2 * (k * 16 + j) + 1];
+        x2r = D[2 * (k * 16 + j + 1)]; x2i = -D[2 * (k * 16 + j + 1) + 1];
+      } else {        // x = Z[j][k], Z[j+1][k]
+        x1r = Z[2 * (j * 16 + k)];       x1i = Z[2 * (j * 16 + k) + 1];
+        x2r = Z[2 * ((j + 1) * 16 + k)]; x2i = Z[2 * ((j + 1) * 16 + k) + 1];
+      }
+      const double y1r = r * x1r - (qr * x2r + qi * x2i), y1i = r * x1i - (qr * x2i - qi * x2r);   // conj(q) x2
+      const double y2r = p * x2r - (qr * x1r - qi * x1i), y2i = p * x2i - (qr * x1i + qi * x1r);   // q x1
+      const double ur = (a1r * y1r - a1i * y1i) + (a2r * y2r - a2i * y2i);
+      const double ui = (a1r * y1i + a1i * y1r) + (a2r * y2i + a2i * y2r);
+      double* T = (g == 0) ? D : Z;
+      T[2 * e] -= ur * dinv;
+      T[2 * e + 1] -= ui * dinv;
+    }
+    __syncthreads();
+  }
+  // final scaling with each pivot block's own Cholesky factor [[l11, 0], [l21, l22]]
+  {
+    const int pj = ((g == 0) ? k : i) & ~1;    // first column (D) / row (Z) of the entry's pivot block
+    double p = D[2 * (pj * 16 + pj)], r = D[2 * ((pj + 1) * 16 + pj + 1)];
+    const double qr = D[2 * ((pj + 1) * 16 + pj)], qi = D[2 * ((pj + 1) * 16 + pj) + 1];
+    p = (p > 0.0) ? p : 1.0;
+    double i11 = __builtin_amdgcn_rsq(p);
+    i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
+    i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
+    const double l21r = qr * i11, l21i = qi * i11;
+    double s22 = r - (l21r * l21r + l21i * l21i);
+    s22 = (s22 > 0.0) ? s22 : 1.0;
+    double i22 = __builtin_amdgcn_rsq(s22);
+    i22 = i22 * fma(-0.5 * s22 * i22, i22, 1.5);
+    i22 = i22 * fma(-0.5 * s22 * i22, i22, 1.5);
+    if (g == 0) {
+      double lr, li;
+      const bool second = (k & 1) != 0;
+      if (i < k) { lr = 0.0; li = 0.0; }
+      else if (!second) {                       // column pj
+        if (i == pj) { lr = p * i11; li = 0.0; }
+        else if (i == pj + 1) { lr = l21r; li = l21i; }
+        else { lr = D[2 * e] * i11; li = D[2 * e + 1] * i11; }
+      } else {                                  // column pj+1
+        if (i == pj + 1) { lr = s22 * i22; li = 0.0; }
+        else {   // (a2 - (a1 / l11) conj(l21)) / l22
+          const double a1r = D[2 * (i * 16 + pj)] * i11, a1i = D[2 * (i * 16 + pj) + 1] * i11;
+          lr = (D[2 * e] - (a1r * l21r + a1i * l21i)) * i22;
+          li = (D[2 * e + 1] - (a1i * l21r - a1r * l21i)) * i22;
+        }
+      }
+      LdR[i * TL_LD + k] = lr;
+      LdI[i * TL_LD + k] = li;
+    } else {   // W rows of the block: W[pj] = Z[pj] / l11,  W[pj+1] = (Z[pj+1] - l21 W[pj]) / l22;  stored as W^H
+      double wr = 0.0, wi = 0.0;
+      if (k <= i) {
+        const double z1r = Z[2 * (pj * 16 + k)] * i11, z1i = Z[2 * (pj * 16 + k) + 1] * i11;
+        if ((i & 1) == 0) { wr = z1r; wi = z1i; }
+        else {
+          wr = (Z[2 * e] - (l21r * z1r - l21i * z1i)) * i22;
+          wi = (Z[2 * e + 1] - (l21r * z1i + l21i * z1r)) * i22;
+        }
+      }
+      WtR[k * TL_LD + i] = wr;
+      WtI[k * TL_LD + i] = -wi;
+    }
+  }
+  __syncthreads();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Tile Cholesky through memory, for systems too large for the register file (eaqhm_ls_mfma_kernel).
+//
+// Stacked, padded system of order 16*nt, nt = 2*nbk + 1, nbk = ceil(Kc/16): tile rows [0, nbk) = amplitude block,
+// [nbk, 2 nbk) = slope block (each padded to 16*nbk with identity rows/columns), tile row 2*nbk = right-hand-side
+// row (row 0; rows 1..15 identity padding).  Only tiles P >= Q are stored: tile (P,Q) at T + tile_off(P,Q), real
+// plane [256] then imaginary plane [256].  Before its column is factorised a tile holds the Hermitian block
+// row-major [row][col] (the MFMA accumulator order: lane l, register r <-> index 64 r + l); afterwards it holds
+// L[P][Q] k-major [col][row], the order in which the MFMA operand loads of later columns are coalesced.
+//
+// Left-looking: column Q first gathers  T[P][Q] - sum_{j<Q} L[P][j] L[Q][j]^H  for its tiles (MFMA, three real
+// products per complex one, operands straight from memory), then the diagonal tile is factorised and inverted in
+// LDS by the whole workgroup (diag_coop) and the panel tiles are multiplied by the inverse (MFMA) and stored.
+// The right-hand side rides along as the last tile row, so the forward substitution is free; the back
+// substitution walks the tile columns from the stored factor.
+#define CH_MB 6          // tiles per wave and column: nt <= 8 * CH_MB
+__device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
+#define CH_LDS_DOUBLES (512 + 512 + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * 8 * CH_MB + 32)
+
+// T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
+__device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, int nt, int Kc, int nbk,
+                                            double* lds, double* xs) {
+  const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* Dc = lds;
+  double* Zc = Dc + 512;
+  double* WtR = Zc + 512;
+  double* WtI = WtR + TL_TILE;
+  double* LdR = WtI + TL_TILE;
+  double* LdI = LdR + TL_TILE;
+  double* trb = LdI + TL_TILE + (size_t)wave * 2 * TL_TILE;   // this wave's transposition buffer
+  double* zv = LdI + TL_TILE + 8 * 2 * TL_TILE;
+  double* xv = zv + 2 * 16 * 8 * CH_MB;
+
+  for (int Q = 0; Q < nt; ++Q) {
+    d4 p1[CH_MB], p2[CH_MB], p3[CH_MB];
+#pragma unroll
+    for (int m = 0; m < CH_MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
+    for (int j = 0; j < Q; ++j) {
+      const double* Bt = T + tile_off(Q, j);
+      double bR[4], bI[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { const int o = (4 * ks + lq) * 16 + lcol; bR[ks] = Bt[o]; bI[ks] = Bt[256 + o]; }
+#pragma unroll
+      for (int m = 0; m < CH_MB; ++m) {
+        const int P = Q + wave + 8 * m;
+        if (P >= nt) continue;
+        const double* At = T + tile_off(P, j);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int o = (4 * ks + lq) * 16 + lcol;
+          const double aR = At[o], aI = At[256 + o];
+          p1[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR[ks], p1[m], 0, 0, 0);
+          p2[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI[ks], p2[m], 0, 0, 0);
+          p3[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI[ks] - bR[ks], p3[m], 0, 0, 0);
+        }
+      }
+    }
+    // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3)
+#pragma unroll
+    for (int m = 0; m < CH_MB; ++m) {
+      const int P = Q + wave + 8 * m;
+      if (P >= nt) continue;
+      const double* Ct = T + tile_off(P, Q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (lq + 4 * r) * 16 + lcol;
+        const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
+        const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
+        p1[m][r] = cr; p3[m][r] = ci;
+      }
+    }
+    if (wave == 0) {   // the diagonal tile is this wave's m = 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Dc[2 * ((lq + 4 * r) * 16 + lcol)] = p1[0][r];
+        Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = p3[0][r];
+      }
+    }
+    __syncthreads();
+    diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid);   // ends with a barrier
+    for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
+    // panel tiles: X = C W^H (three real products), stored k-major
+#pragma unroll
+    for (int m = 0; m < CH_MB; ++m) {
+      const int P = Q + wave + 8 * m;
+      if (P >= nt || P == Q) continue;
+      double* tr = trb;
+      double* ti = trb + TL_TILE;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // C[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
+        tr[lcol * TL_LD + lq + 4 * r] = p1[m][r];
+        ti[lcol * TL_LD + lq + 4 * r] = p3[m][r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      d4 x1 = (d4){0, 0, 0, 0}, x2 = (d4){0, 0, 0, 0}, x3 = (d4){0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int o = (4 * ks + lq) * TL_LD + lcol;
+        const double aR = tr[o], aI = ti[o], bR = WtR[o], bI = WtI[o];
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, x2, 0, 0, 0);
+        x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bR + bI, x3, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      double* Lt = T + tile_off(P, Q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // L[i = lq+4r][k = lcol] -> [k][i]
+        Lt[lcol * 16 + lq + 4 * r] = x1[r] - x2[r];
+        Lt[256 + lcol * 16 + lq + 4 * r] = x3[r] - (x1[r] + x2[r]);
+      }
+    }
+    __syncthreads();   // factor column visible to every wave; Dc / Wt reusable
+  }
+
+  // ---- back substitution  L^H x = y,  y = conj(row 0 of the last tile row)
+  for (int q = tid; q < 16 * (nt - 1); q += blockDim.x) {
+    const int Qt = q >> 4, c = q & 15;
+    const double* Lt = T + tile_off(nt - 1, Qt);
+    zv[2 * q] = Lt[c * 16];
+    zv[2 * q + 1] = -Lt[256 + c * 16];
+  }
+  for (int q = tid; q < 4 * Kc; q += blockDim.x) xs[q] = 0.0;
+  __syncthreads();
+  for (int P = nt - 2; P >= 0; --P) {
+    if (tid < 256) {  // x_P = W_PP^H z_P : thread (i, k) takes one term of row i, 16-lane shuffle reduction
+      const int i = tid >> 4, k = tid & 15;
+      double xr = 0, xi = 0;
+      if (k >= i) {   // W^H is upper triangular
+        const double wr = WT[(size_t)P * 2 * TL_TILE + i * TL_LD + k], wi = WT[(size_t)P * 2 * TL_TILE + TL_TILE + i * TL_LD + k];
+        const double zr = zv[2 * (16 * P + k)], zi = zv[2 * (16 * P + k) + 1];
+        xr = wr * zr - wi * zi;
+        xi = wr * zi + wi * zr;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { xr += __shfl_xor(xr, o); xi += __shfl_xor(xi, o); }
+      if (k == 0) {
+        xv[2 * i] = xr; xv[2 * i + 1] = xi;
+        const int q = (P < nbk) ? (16 * P + i) : (16 * (P - nbk) + i);   // amplitudes, then slopes
+        if (q < Kc) { const int d = (P < nbk) ? q : (Kc + q); xs[2 * d] = xr; xs[2 * d + 1] = xi; }
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < 16 * P; q += blockDim.x) {   // z_Q -= L[P][Q]^H x_P
+      const int Qt = q >> 4, c = q & 15;
+      const double* Lt = T + tile_off(P, Qt) + c * 16;
+      double sr = 0, si = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double lr = Lt[i], li = Lt[256 + i], xr = xv[2 * i], xi = xv[2 * i + 1];
+        sr += lr * xr + li * xi;
+        si += lr * xi - li * xr;
+      }
+      zv[2 * q] -= sr;
+      zv[2 * q + 1] -= si;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace eaqhm

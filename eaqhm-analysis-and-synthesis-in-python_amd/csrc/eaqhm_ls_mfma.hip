@@ -17,10 +17,9 @@
 //   C    system matrix [[G0,G1],[G1,G2]] + RHS row -> scratch, Cholesky + back substitution
 //   D    frequency mismatch, acceptance, record row                                     (eaqhm_ls_common.h)
 #include "eaqhm_ls_common.h"
+#include "eaqhm_ls_chol.h"
 
 namespace eaqhm {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MF_THREADS 512
 #define MF_WAVES 8
@@ -29,12 +28,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct MfScratch {
   double* Q;   // (Nmax+1) * nmax
   double* r;   // (Nmax+1) * nmax
-  double* Lt;  // Mmax * (Mmax+1) * 2
+  double* T;   // stacked padded system, 16x16 complex tiles (eaqhm_ls_chol.h)
+  double* WT;  // inverse diagonal tiles
 };
 
+__host__ __device__ inline size_t mf_tile_doubles(int Kcmax) {
+  const size_t nt = 2 * (((size_t)Kcmax + 15) / 16) + 1;
+  return nt * (nt + 1) / 2 * 512;
+}
 __host__ __device__ inline size_t mf_scratch_doubles(int nmax, int Nmax, int Kcmax) {
-  size_t M = 2 * (size_t)Kcmax;
-  return 2 * (size_t)(Nmax + 1) * nmax + 2 * M * (M + 1);
+  const size_t nt = 2 * (((size_t)Kcmax + 15) / 16) + 1;
+  return 2 * (size_t)(Nmax + 1) * nmax + mf_tile_doubles(Kcmax) + nt * 2 * TL_TILE;
 }
 
 __device__ inline void tile_of(int q, int& I, int& J) {
@@ -64,7 +68,8 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     double* base = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
     S.Q = base;
     S.r = S.Q + (size_t)(A.Nmax + 1) * A.nmax;
-    S.Lt = S.r + (size_t)(A.Nmax + 1) * A.nmax;
+    S.T = S.r + (size_t)(A.Nmax + 1) * A.nmax;
+    S.WT = S.T + mf_tile_doubles(A.Kcmax);
   }
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
   for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // finite everywhere (rows with weight 0)
@@ -83,7 +88,8 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
     const int N = 2 * wl + 1, mid = wl;
     const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
-    const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc, ldl = M + 1;
+    const int Kc = 2 * n + 1, C1 = Kc + 1;
+    const int nbk = (Kc + 15) >> 4, ntl = 2 * nbk + 1;   // stacked padded tile rows (eaqhm_ls_chol.h)
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
     const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
@@ -92,12 +98,18 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 
+    for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // the factorisation used this region as work space
     if (A.mode == 1) fill_columns(A, S.Q, S.r, rho, mycols, n, N, mid, c, wl, seeds);
     // padding columns of this frame must be zero
     for (int q = tid; q < TS * (C1p - C1); q += nt) {
       int row = q / (C1p - C1), col = C1 + q - row * (C1p - C1);
       Xre[row * ldx + col] = 0.0;
       Xim[row * ldx + col] = 0.0;
+    }
+    // right-hand-side tile row: zero, its diagonal tile the identity (row 0 is filled from the signal row below)
+    for (int q = tid; q < ntl * 512; q += nt) {
+      const int Qt = q >> 9, e = q & 511;
+      S.T[tile_off(ntl - 1, Qt) + e] = (Qt == ntl - 1 && e < 256 && (e >> 4) == (e & 15)) ? 1.0 : 0.0;
     }
     __syncthreads();
 
@@ -196,38 +208,45 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
         __syncthreads();
       }
 
-      // ---- accumulators -> transposed system matrix Lt[col][row] (R = [[G0,G1],[G1,G2]], RHS row M)
+      // ---- accumulators -> tiles of the stacked padded system [[G0,G1^H],[G1,G2]] + RHS row (eaqhm_ls_chol.h).
+      // Base tiles are aligned with the stacked ones; positions beyond Kc inside a block are identity padding.
 #pragma unroll
       for (int sl = 0; sl < MF_NSLOT; ++sl) {
         if (!live[sl]) continue;
         const int I = tI[sl], J = tJ[sl], p = wsel[sl];
-        const int b = 16 * J + (lane & 15);
+        const int bl = lane & 15, b = 16 * J + bl;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const int a = 16 * I + (lane >> 4) + 4 * rr;
+          const int al = (lane >> 4) + 4 * rr, a = 16 * I + al;
           const double gr = accR[sl][rr], gi = accI[sl][rr];
-          auto put = [&](int row, int col, double re, double im) {
-            size_t o = ((size_t)col * ldl + row) * 2;
-            S.Lt[o] = re; S.Lt[o + 1] = im;
-          };
-          if (b >= Kc) continue;
-          if (a < Kc) {
-            if (p == 0) { if (a >= b) put(a, b, gr, gi); }
-            else if (p == 2) { if (a >= b) put(Kc + a, Kc + b, gr, gi); }
-            else {
-              put(Kc + a, b, gr, gi);
-              if (I != J) put(Kc + b, a, gr, -gi);
+          if (a == Kc) {   // signal row: conj(rhs) into row 0 of the RHS tile row, its energy on the diagonal
+            if (b < Kc && p == 0) { double* t = S.T + tile_off(ntl - 1, J) + bl; t[0] = gr; t[256] = gi; }
+            if (b < Kc && p == 1) { double* t = S.T + tile_off(ntl - 1, nbk + J) + bl; t[0] = gr; t[256] = gi; }
+            if (b == Kc && p == 0) { double* t = S.T + tile_off(ntl - 1, ntl - 1); t[0] = gr; t[256] = 0.0; }
+          }   // ... and inside the blocks the signal's row / column is one more identity padding position
+          if (I >= nbk || J >= nbk) continue;   // the base tile row / column that holds only the signal
+          const bool in = (a < Kc) && (b < Kc);
+          if (p == 0 || p == 2) {
+            const int o = (p == 0) ? 0 : nbk;
+            double* t = S.T + tile_off(o + I, o + J) + al * 16 + bl;
+            t[0] = in ? gr : ((a == b) ? 1.0 : 0.0);
+            t[256] = in ? gi : 0.0;
+          } else {   // cross block: G1 is Hermitian, the stacked system needs all of it
+            double* t = S.T + tile_off(nbk + I, J) + al * 16 + bl;
+            t[0] = in ? gr : 0.0;
+            t[256] = in ? gi : 0.0;
+            if (I != J) {
+              double* u = S.T + tile_off(nbk + J, I) + bl * 16 + al;
+              u[0] = in ? gr : 0.0;
+              u[256] = in ? -gi : 0.0;
             }
-          } else if (a == Kc) {  // signal row: conj(rhs) (see gram_to_system in eaqhm_ls.hip)
-            if (p == 0) put(M, b, gr, gi);
-            else if (p == 1) put(M, Kc + b, gr, gi);
           }
         }
       }
     }
     __syncthreads();
 
-    cholesky_solve(S.Lt, M, ldl, rowj, xs, sh);
+    tile_cholesky_memory(S.T, S.WT, ntl, Kc, nbk, Xre, xs);
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
   }
 }
@@ -240,12 +259,15 @@ size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax) {
 int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   const int nmax = A.nmax, Kcmax = A.Kcmax;
   const int nbmax = (Kcmax + 1 + 15) / 16;
-  const int ldx_max = 16 * nbmax + 16;
+  int ldx_max = 16 * nbmax + 16;
+  if (ldx_max * 64 < CH_LDS_DOUBLES) ldx_max = (CH_LDS_DOUBLES / 64 + 15) & ~15;   // the factorisation reuses the chunk planes
   const size_t fixed = (size_t)(2 * nmax + 4 * (2 * Kcmax) + 16) * sizeof(double);
   int TS = 32;
   while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 150 * 1024) TS >>= 1;
   const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
+  if ((size_t)2 * TS * ldx_max < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > 8 * CH_MB)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the tile factorisation's work space");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
   hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, min_nb);

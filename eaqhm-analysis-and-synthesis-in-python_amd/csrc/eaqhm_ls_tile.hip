@@ -26,17 +26,15 @@
 // Frames with more than 13 tile rows (Kc > 103) do not fit the register budget and are left to
 // eaqhm_ls_mfma_kernel (same Gramian, factorisation through scratch memory).
 #include "eaqhm_ls_common.h"
+#include "eaqhm_ls_chol.h"
 
 namespace eaqhm {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define TL_THREADS 512
 #define TL_WAVES 8
 #define TL_CW 8         // all waves own tiles
 #define TL_NTMAX 13
-#define TL_LD 17        // tile row stride in LDS (doubles): conflict-free transposing stores
-#define TL_TILE (16 * TL_LD)
 #define CI_STRIDE 20    // per-slot info: 16 chunk carries, qmid, 1/(am_mid+eps), rho.re, rho.im
 #define CI_NCH 16
 #define XCOL(cc, el) (((cc) & ~15) | (((cc) + (el)) & 15))
@@ -148,103 +146,6 @@ __device__ inline double scan16(double x) {
   x += dpp_row<0x114>(x);  // row_shr:4
   x += dpp_row<0x118>(x);  // row_shr:8
   return x;
-}
-
-// ---- diagonal tile: Cholesky factor L and W = L^-1 of a 16x16 Hermitian positive definite tile, by the whole
-// workgroup.  The sixteen column steps are a serial chain on the critical path of the frame, so each step is
-// made as short as possible: one thread per matrix entry (threads 0-255: D, threads 256-511: the inverse by
-// forward elimination on [L | I]), three LDS reads, one reciprocal, one complex multiply-add, one barrier.
-//   D  [16][16] complex (interleaved), row-major, lower triangle used;  Z likewise (starts as identity)
-//   outputs: Wt planes hold (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j];  Ld planes hold L[i][j] at [i*TL_LD + j]
-__device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
-  // 2x2 block pivots: seven elimination steps instead of fifteen.  With P = [[p, conj(q)], [q, r]] the pivot block
-  // of columns (j, j+1) and a = D[i][j..j+1], b = D[k][j..j+1]:   D[i][k] -= a P^-1 b^H   (i >= k >= j+2), and
-  // the rows of the inverse below the block follow the same elimination on [L | I].  Columns / rows inside a
-  // block stay raw until the final scaling, which applies the block's own 2x2 Cholesky factor.
-  const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
-  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
-  __syncthreads();
-#pragma clang loop unroll(disable)
-  for (int j = 0; j < 14; j += 2) {
-    const bool work = (g == 0) ? (k >= j + 2 && i >= k) : (i >= j + 2 && k <= j + 1);
-    if (work) {
-      double p = D[2 * (j * 16 + j)], r = D[2 * ((j + 1) * 16 + j + 1)];
-      const double qr = D[2 * ((j + 1) * 16 + j)], qi = D[2 * ((j + 1) * 16 + j) + 1];
-      p = (p > 0.0) ? p : 1.0;
-      double det = p * r - (qr * qr + qi * qi);
-      det = (det > 0.0) ? det : 1.0;   // only the RHS position of the last tile can get here (residual ~ 0)
-      double dinv = __builtin_amdgcn_rcp(det);
-      dinv = dinv * fma(-det, dinv, 2.0);
-      dinv = dinv * fma(-det, dinv, 2.0);
-      const double a1r = D[2 * (i * 16 + j)], a1i = D[2 * (i * 16 + j) + 1];
-      const double a2r = D[2 * (i * 16 + j + 1)], a2i = D[2 * (i * 16 + j + 1) + 1];
-      // y = P^-1 [x1; x2] * det = [ r x1 - conj(q) x2 ;  -q x1 + p x2 ],  then  out -= (a1 y1 + a2 y2) / det
-      double x1r, x1i, x2r, x2i;
-      if (g == 0) {   // x = b^H components: conj(D[k][j]), conj(D[k][j+1])
-        x1r = D[2 * (k * 16 + j)];     x1i = -D[2 * (k * 16 + j) + 1];
-        x2r = D[2 * (k * 16 + j + 1)]; x2i = -D[2 * (k * 16 + j + 1) + 1];
-      } else {        // x = Z[j][k], Z[j+1][k]
-        x1r = Z[2 * (j * 16 + k)];       x1i = Z[2 * (j * 16 + k) + 1];
-        x2r = Z[2 * ((j + 1) * 16 + k)]; x2i = Z[2 * ((j + 1) * 16 + k) + 1];
-      }
-      const double y1r = r * x1r - (qr * x2r + qi * x2i), y1i = r * x1i - (qr * x2i - qi * x2r);   // conj(q) x2
-      const double y2r = p * x2r - (qr * x1r - qi * x1i), y2i = p * x2i - (qr * x1i + qi * x1r);   // q x1
-      const double ur = (a1r * y1r - a1i * y1i) + (a2r * y2r - a2i * y2i);
-      const double ui = (a1r * y1i + a1i * y1r) + (a2r * y2i + a2i * y2r);
-      double* T = (g == 0) ? D : Z;
-      T[2 * e] -= ur * dinv;
-      T[2 * e + 1] -= ui * dinv;
-    }
-    __syncthreads();
-  }
-  // final scaling with each pivot block's own Cholesky factor [[l11, 0], [l21, l22]]
-  {
-    const int pj = ((g == 0) ? k : i) & ~1;    // first column (D) / row (Z) of the entry's pivot block
-    double p = D[2 * (pj * 16 + pj)], r = D[2 * ((pj + 1) * 16 + pj + 1)];
-    const double qr = D[2 * ((pj + 1) * 16 + pj)], qi = D[2 * ((pj + 1) * 16 + pj) + 1];
-    p = (p > 0.0) ? p : 1.0;
-    double i11 = __builtin_amdgcn_rsq(p);
-    i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
-    i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
-    const double l21r = qr * i11, l21i = qi * i11;
-    double s22 = r - (l21r * l21r + l21i * l21i);
-    s22 = (s22 > 0.0) ? s22 : 1.0;
-    double i22 = __builtin_amdgcn_rsq(s22);
-    i22 = i22 * fma(-0.5 * s22 * i22, i22, 1.5);
-    i22 = i22 * fma(-0.5 * s22 * i22, i22, 1.5);
-    if (g == 0) {
-      double lr, li;
-      const bool second = (k & 1) != 0;
-      if (i < k) { lr = 0.0; li = 0.0; }
-      else if (!second) {                       // column pj
-        if (i == pj) { lr = p * i11; li = 0.0; }
-        else if (i == pj + 1) { lr = l21r; li = l21i; }
-        else { lr = D[2 * e] * i11; li = D[2 * e + 1] * i11; }
-      } else {                                  // column pj+1
-        if (i == pj + 1) { lr = s22 * i22; li = 0.0; }
-        else {   // (a2 - (a1 / l11) conj(l21)) / l22
-          const double a1r = D[2 * (i * 16 + pj)] * i11, a1i = D[2 * (i * 16 + pj) + 1] * i11;
-          lr = (D[2 * e] - (a1r * l21r + a1i * l21i)) * i22;
-          li = (D[2 * e + 1] - (a1i * l21r - a1r * l21i)) * i22;
-        }
-      }
-      LdR[i * TL_LD + k] = lr;
-      LdI[i * TL_LD + k] = li;
-    } else {   // W rows of the block: W[pj] = Z[pj] / l11,  W[pj+1] = (Z[pj+1] - l21 W[pj]) / l22;  stored as W^H
-      double wr = 0.0, wi = 0.0;
-      if (k <= i) {
-        const double z1r = Z[2 * (pj * 16 + k)] * i11, z1i = Z[2 * (pj * 16 + k) + 1] * i11;
-        if ((i & 1) == 0) { wr = z1r; wi = z1i; }
-        else {
-          wr = (Z[2 * e] - (l21r * z1r - l21i * z1i)) * i22;
-          wi = (Z[2 * e + 1] - (l21r * z1i + l21i * z1r)) * i22;
-        }
-      }
-      WtR[k * TL_LD + i] = wr;
-      WtI[k * TL_LD + i] = -wi;
-    }
-  }
-  __syncthreads();
 }
 
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
