@@ -298,6 +298,23 @@ def test_option_paths_against_oracle(amd, tmp_path):
     assert np.array_equal([d.isVoiced for d in det], ref["isVoiced"])
 
 
+def test_sa19_large_frame_kernel_on_every_frame(amd, sa19_golden):
+    """The large-frame LS kernel (MFMA Gramian in passes, tile Cholesky through memory) forced onto every SA19
+    frame (EAQHM_OPT_LS_VARIANT = 2): three adaptations (modes 0 and 1) against the reference's SRER."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    grid = prologue.resample_track(sa19_golden["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    eng = DeviceAnalysis(s, s, plan, 160, 2)
+    eng.ctx.set_option(1, 2)
+    eng.run()
+    assert len(eng.SRER) == 3
+    assert np.abs(np.array(eng.SRER) - sa19_golden["SRER"][:3]).max() < TOL_SRER_DB
+
+
 def test_48khz_large_frames():
     """BASELINE config 5 in miniature: 0.6 s of the synthetic signal at 48 kHz (N up to 901, Kc up to ~300: the
     frames take the large-frame LS kernel).  Adaptation 0 is pinned against the reference's run; adaptation 1
