@@ -196,8 +196,8 @@ class DeviceAnalysis:
             self.timeline.append((a, "ls", e0, e1))
         self.n_ls_frames += self.nf
 
-    def post_stage(self, a):
-        """Interpolation + synthesis + SRER of adaptation `a`; returns the SRER (host float)."""
+    def post_launch(self, a):
+        """Enqueue interpolation + synthesis + error sums of adaptation `a` (no host read)."""
         p, c, sh = self.plan, self.ctx, self.shard
         sh.all_gather_rows(self.records[0], p.No_ti)
         e0 = self._mark()
@@ -211,14 +211,23 @@ class DeviceAnalysis:
         e1 = self._mark()
         if self.profile:
             self.timeline.append((a, "post", e0, e1))
+
+    def post_result(self):
+        """SRER of the adaptation enqueued last (host float): the one device->host read of an adaptation."""
+        p, sh = self.plan, self.shard
         if not sh.collective:
-            return float(self.sums[3].item())   # the one device->host read of the adaptation
+            return float(self.sums[3].item())
         red = self.sums[:2].clone()
         sh.all_reduce_sum(red)
         tot, tot2 = (float(v) for v in red.cpu())
         n = float(p.L)
         mean = tot / n
         return float(20.0 * np.log10(self.std_det / np.sqrt(tot2 / n - mean * mean)))
+
+    def post_stage(self, a):
+        """Interpolation + synthesis + SRER of adaptation `a`; returns the SRER (host float)."""
+        self.post_launch(a)
+        return self.post_result()
 
     def reset(self, keep_timeline=False):
         """Forget the previous run (the buffers are rewritten by the next one)."""
@@ -229,13 +238,19 @@ class DeviceAnalysis:
             self.timeline = []
             self.ncol_hist = []
 
-    def run(self, on_adaptation=None):
-        """functions.py:163-402.  Returns the number of executed adaptations."""
+    def adaptations(self, on_adaptation=None):
+        """functions.py:163-402 as a generator: yields once per adaptation, right after its kernels have been
+        enqueued and before the host reads its SRER, so that a caller driving several analyses (run_interleaved)
+        can enqueue the others' work before this one blocks."""
         if hasattr(self.ctx, "bind_stream"):
             self.ctx.bind_stream()
         for a in range(self.max_adpt + 1):
             self.ls_stage(a)
-            srer = self.post_stage(a)
+            self.post_launch(a)
+            yield a
+            if hasattr(self.ctx, "bind_stream"):
+                self.ctx.bind_stream()
+            srer = self.post_result()
             self.SRER.append(np.float64(srer))
             if on_adaptation is not None:
                 on_adaptation(a, self)
@@ -252,6 +267,11 @@ class DeviceAnalysis:
             # accept: functions.py:397-402
             for buf in (self.records, self.ph_knot, self.s_hat):
                 buf[0], buf[1] = buf[1], buf[0]
+
+    def run(self, on_adaptation=None):
+        """Runs the adaptation loop to its end.  Returns the number of executed adaptations."""
+        for _ in self.adaptations(on_adaptation):
+            pass
         return len(self.SRER)
 
     # ------------------------------------------------------------------ results
@@ -285,3 +305,30 @@ class DeviceAnalysis:
         for a, stage, e0, e1 in self.timeline:
             acc.setdefault(stage, []).append(e0.elapsed_time(e1))
         return acc
+
+
+def run_interleaved(engines, on_adaptation=None):
+    """Batch operation: the adaptation loops of several independent analyses on ONE GPU, each on
+    its own HIP stream, advanced round-robin.  While the host waits for the SRER of one analysis the kernels of
+    the others are already queued, so launch tails and the per-adaptation host round trip of one file are filled
+    with the frames of the next.  Results are bit-identical to running the engines one after another (same
+    kernels, same inputs; the analyses share nothing but the device)."""
+    if not engines:
+        return
+    torch = engines[0].torch
+    main = torch.cuda.current_stream(engines[0].ctx.device)
+    jobs = []
+    for i, e in enumerate(engines):
+        st = torch.cuda.Stream(device=e.ctx.device)
+        st.wait_stream(main)                      # inputs were uploaded on the current stream
+        cb = (lambda a, eng, i=i: on_adaptation(i, a, eng)) if on_adaptation is not None else None
+        jobs.append((e, st, e.adaptations(cb)))
+    while jobs:
+        for job in list(jobs):
+            e, st, gen = job
+            with torch.cuda.stream(st):
+                try:
+                    next(gen)
+                except StopIteration:
+                    jobs.remove(job)
+                    main.wait_stream(st)          # final_arrays() reads on the current stream

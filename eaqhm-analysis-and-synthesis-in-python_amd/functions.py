@@ -44,6 +44,27 @@ def _slot_array(slots, values):
     return out
 
 
+def _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc, partials,
+             pitch_track, device_index):
+    """functions.py:86-146: everything before the adaptation loop -> (plan, engine)."""
+    fs, s = prologue.read_signal(speechFile, fc)                                 # functions.py:86-91
+    length = len(s)
+    f0min, f0max = prologue.pitch_limits(gender)                                 # functions.py:95-109
+    if pitch_track is None:
+        from .swipe import swipep
+        pitch_track = swipep(s, fs, [f0min, f0max])                              # functions.py:111
+    grid_t = np.arange(0, length - 1, round(fs * 5 / 1000)) / fs
+    f0_grid = prologue.resample_track(pitch_track, grid_t)                       # functions.py:113
+    frames, frame_step = prologue.voiced_unvoiced_frames(s, fs, gender)          # functions.py:125
+    if fullWaveform:
+        prologue.apply_full_waveform(frames, length, analysisWindow * step)      # functions.py:139-146
+        target = s
+    else:
+        target = prologue.voiced_only_target(s, frames, frame_step)              # functions.py:127-138
+    plan = FramePlan(length, fs, f0_grid, frames, frame_step, step, pitchPeriods, analysisWindow, partials)
+    return plan, DeviceAnalysis(s, target, plan, f0min, maxAdpt, device_index=device_index)
+
+
 def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', step: int = 15,
                               maxAdpt: int = 10, pitchPeriods: int = 3, analysisWindow: int = 32,
                               fullWaveform: bool = True, fc: int = 0, partials: int = 0,
@@ -60,22 +81,8 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
       device_index  which GPU of this process to use
     """
     start = time()
-    fs, s = prologue.read_signal(speechFile, fc)                                 # functions.py:86-91
-    length = len(s)
-    f0min, f0max = prologue.pitch_limits(gender)                                 # functions.py:95-109
-    if pitch_track is None:
-        from .swipe import swipep
-        pitch_track = swipep(s, fs, [f0min, f0max])                              # functions.py:111
-    grid_t = np.arange(0, length - 1, round(fs * 5 / 1000)) / fs
-    f0_grid = prologue.resample_track(pitch_track, grid_t)                       # functions.py:113
-    frames, frame_step = prologue.voiced_unvoiced_frames(s, fs, gender)          # functions.py:125
-    if fullWaveform:
-        prologue.apply_full_waveform(frames, length, analysisWindow * step)      # functions.py:139-146
-        target = s
-    else:
-        target = prologue.voiced_only_target(s, frames, frame_step)              # functions.py:127-138
-    plan = FramePlan(length, fs, f0_grid, frames, frame_step, step, pitchPeriods, analysisWindow, partials)
-    eng = DeviceAnalysis(s, target, plan, f0min, maxAdpt, device_index=device_index)
+    plan, eng = _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc,
+                         partials, pitch_track, device_index)
 
     state = {"t": time()}
 
@@ -95,6 +102,39 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
         print('Total Time: {}\n\n'.format(strftime("%H:%M:%S", gmtime(end_time))))
     out = (fin["s_recon"], list(eng.SRER), det, end_time)
     return out + (eng,) if _return_engine else out
+
+
+def eaQHMAnalysisAndSynthesisBatch(speechFiles, gender: str or tuple = 'other', step: int = 15,
+                                   maxAdpt: int = 10, pitchPeriods: int = 3, analysisWindow: int = 32,
+                                   fullWaveform: bool = True, fc: int = 0, partials: int = 0,
+                                   printPrompts: bool = False, *, pitch_tracks=None, device_index: int = 0):
+    """Several files in one go on one GPU (not in the reference).  Every file gets exactly the
+    result eaQHMAnalysisAndSynthesis() gives it — the analyses are independent, each keeps its own stop rule — but
+    their adaptation loops are interleaved on separate HIP streams (engine.run_interleaved), which keeps the GPU
+    busy across the launch tails and host round trips of short files.  `gender` (and `pitch_tracks`) may be one
+    value for all files or a list with one entry per file.  Returns a list of (s_recon, SRER, DetComponents,
+    endTime) tuples in input order; endTime is the batch's wall time."""
+    from .engine import run_interleaved
+    start = time()
+    files = list(speechFiles)
+    genders = list(gender) if isinstance(gender, list) else [gender] * len(files)
+    tracks = list(pitch_tracks) if pitch_tracks is not None else [None] * len(files)
+    if len(genders) != len(files) or len(tracks) != len(files):
+        raise ValueError("gender / pitch_tracks lists must have one entry per file")
+    jobs = [_prepare(f, g, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc, partials, t, device_index)
+            for f, g, t in zip(files, genders, tracks)]
+
+    def report(i, a, e):
+        if printPrompts:
+            print('[{}] SRER: {} dB in Adaptation No: {}'.format(files[i], e.SRER[a], a))
+
+    run_interleaved([e for _, e in jobs], on_adaptation=report)
+    out = []
+    for plan, eng in jobs:
+        fin = eng.final_arrays()
+        out.append((fin["s_recon"], list(eng.SRER), pack_results(plan, fin)))
+    end_time = time() - start
+    return [o + (end_time,) for o in out]
 
 
 def pack_results(plan, fin):

@@ -315,6 +315,32 @@ def test_sa19_large_frame_kernel_on_every_frame(amd, sa19_golden):
     assert np.abs(np.array(eng.SRER) - sa19_golden["SRER"][:3]).max() < TOL_SRER_DB
 
 
+def test_batch_matches_single_file_runs(amd, sa19_golden, tmp_path):
+    """several files interleaved on separate streams give every file exactly the result of its own
+    run (bitwise: same kernels, same inputs), each with its own number of executed adaptations."""
+    import scipy.io.wavfile as wavfile
+    from eaqhm_amd.synth import synth_speech_int16
+    fs = 16000
+    x = synth_speech_int16(0.8, fs)
+    wav2 = str(tmp_path / "synth.wav")
+    wavfile.write(wav2, fs, x)
+    t = np.arange(0, len(x) / fs, 0.001)
+    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    track2 = np.column_stack([t, f0])
+    wav1 = os.path.join(GOLDEN, "SA19.WAV")
+    files, tracks = [wav1, wav2, wav1], [sa19_golden["swipe_track"], track2, sa19_golden["swipe_track"]]
+    kw = dict(maxAdpt=3, printPrompts=False)
+    single = [amd.eaQHMAnalysisAndSynthesis(f, "female", pitch_track=tr, **kw) for f, tr in zip(files[:2], tracks[:2])]
+    batch = amd.eaQHMAnalysisAndSynthesisBatch(files, "female", pitch_tracks=tracks, **kw)
+    assert len(batch) == 3
+    for b, ref in zip(batch, [single[0], single[1], single[0]]):
+        assert np.array_equal(b[0], ref[0])
+        assert [float(v) for v in b[1]] == [float(v) for v in ref[1]]
+        assert len(b[2]) == len(ref[2])
+        assert all(np.array_equal(np.asarray(p.a0), np.asarray(q.a0)) for p, q in zip(b[2][::97], ref[2][::97]))
+    assert np.abs(np.array(batch[0][1]) - sa19_golden["SRER"][:4]).max() < TOL_SRER_DB
+
+
 def test_48khz_large_frames():
     """BASELINE config 5 in miniature: 0.6 s of the synthetic signal at 48 kHz (N up to 901, Kc up to ~300: the
     frames take the large-frame LS kernel).  Adaptation 0 is pinned against the reference's run; adaptation 1
