@@ -128,14 +128,31 @@ struct EvalArgs {
   const double* target; double* am_out; double* fm_out; double* ph_knot; double* s_hat; double* partials;
 };
 
+// Rows [r0, r1] of records / code / mom staged in LDS by the block (eaqhm_eval_kernel); anything outside (only the
+// padded <4-knot case reaches back to rows 0..3) is read from memory.
+struct RowCache {
+  const double* rec; const double* mom; const unsigned char* code; int r0, r1;
+};
+
 struct Slot {
   const EvalArgs& A;
+  const RowCache& C;
   int k;
-  __device__ double am(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + k]; }
-  __device__ double fm(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + A.Kmax + k]; }
-  __device__ double ph(int i) const { return A.records[(size_t)i * (3 * A.Kmax + 1) + 2 * A.Kmax + k]; }
-  __device__ int code(int i) const { return (i >= 0 && i < A.No_ti) ? A.code[(size_t)i * A.Kmax + k] : 0; }
-  __device__ double mom(int i) const { return A.mom[(size_t)i * (A.Kmax + 1) + k]; }
+  __device__ bool in(int i) const { return i >= C.r0 && i <= C.r1; }
+  __device__ double recv(int i, int col) const {
+    const int RS = 3 * A.Kmax + 1;
+    return in(i) ? C.rec[(size_t)(i - C.r0) * RS + col] : A.records[(size_t)i * RS + col];
+  }
+  __device__ double am(int i) const { return recv(i, k); }
+  __device__ double fm(int i) const { return recv(i, A.Kmax + k); }
+  __device__ double ph(int i) const { return recv(i, 2 * A.Kmax + k); }
+  __device__ int code(int i) const {
+    if (i < 0 || i >= A.No_ti) return 0;
+    return in(i) ? C.code[(size_t)(i - C.r0) * A.Kmax + k] : A.code[(size_t)i * A.Kmax + k];
+  }
+  __device__ double mom(int i) const {
+    return in(i) ? C.mom[(size_t)(i - C.r0) * (A.Kmax + 1) + k] : A.mom[(size_t)i * (A.Kmax + 1) + k];
+  }
 };
 
 // cubic piece of the interval (i, i+1) at offset r samples from knot i
@@ -209,19 +226,37 @@ __device__ inline double unwrap_diff(double dd) {
 //   stage 2  one thread per (sample, slot group): amplitudes, next-iteration frequency from the unwrapped phase
 //            (functions.py:375), knot bookkeeping, am*cos(ph) into LDS; then one thread per sample adds the
 //            slots in slot order, the a0 spline and the reconstruction error (functions.py:385-388).
-extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, int TBS, int NK) {
+extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, int TBS, int NK, int NR) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int D = A.step, K = A.Kmax;
   double* ft = lds;                           // D+1
-  double* X1 = lds + ((D + 1 + 1) & ~1);      // [K][TBS]
-  double* X2 = X1 + (size_t)K * TBS;          // [K][TBS]
-  double* X3 = X2 + (size_t)K * TBS;          // [K][NK]
+  double* X1 = lds + ((D + 1 + 1) & ~1);      // [K][TP]
+  const int TP = TBS + 1;                     // row stride: stage 1 writes a column of slots at once (bank spread)
+  double* X2 = X1 + (size_t)K * TP;           // [K][TP]
+  double* X3 = X2 + (size_t)K * TP;           // [K][NK]
+  double* crec = X3 + (size_t)K * NK;         // [NR][3K+1]   staged rows of the records
+  double* cmom = crec + (size_t)NR * (3 * K + 1);                    // [NR][K+1]
+  unsigned char* ccode = (unsigned char*)(cmom + (size_t)NR * (K + 1));   // [NR][K]
   const int tid = threadIdx.x;
-  for (int u = tid; u <= D; u += blockDim.x) ft[u] = sin(M_PI * (double)u / (double)D);
-  __syncthreads();
   const long long t0 = A.t_lo + (long long)blockIdx.x * TBS;
   const long long t1 = (t0 + TBS < A.t_hi) ? (t0 + TBS) : A.t_hi;      // block covers [t0, t1)
   const long long tk0 = ((t0 + D - 1) / D) * D;                        // first knot at or after t0
+  // the instants this block touches: one before its first interval to two after its last (coalesced rows)
+  RowCache C;
+  {
+    const int jlo = (int)((t0 > 0) ? ((t0 - 1) / D) : 0), jhi = (int)((t1 - 1) / D);
+    C.r0 = (jlo > 0) ? jlo - 1 : 0;
+    C.r1 = (jhi + 2 < A.No_ti) ? jhi + 2 : A.No_ti - 1;
+    if (C.r1 > C.r0 + NR - 1) C.r1 = C.r0 + NR - 1;
+    if (C.r1 < C.r0) C.r1 = C.r0 - 1;   // nothing staged (block beyond the last instant)
+    C.rec = crec; C.mom = cmom; C.code = ccode;
+    const int nrow = C.r1 - C.r0 + 1, RS = 3 * K + 1;
+    for (int q = tid; q < nrow * RS; q += blockDim.x) crec[q] = A.records[(size_t)C.r0 * RS + q];
+    for (int q = tid; q < nrow * (K + 1); q += blockDim.x) cmom[q] = A.mom[(size_t)C.r0 * (K + 1) + q];
+    for (int q = tid; q < nrow * K; q += blockDim.x) ccode[q] = A.code[(size_t)C.r0 * K + q];
+  }
+  for (int u = tid; u <= D; u += blockDim.x) ft[u] = sin(M_PI * (double)u / (double)D);
+  __syncthreads();
   // ---- stage 1: intervals (j, j+1) whose samples j*D .. (j+1)*D meet the block
   {
     const int jlo = (int)((t0 > 0) ? ((t0 - 1) / D) : 0), jhi = (int)((t1 - 1) / D);
@@ -230,7 +265,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
     for (int p = tid; p < nint * K; p += blockDim.x) {
       const int jj = p / K, k = p - jj * K, j = jlo + jj;
       if (j + 1 >= A.No_ti) continue;
-      Slot S{A, k};
+      Slot S{A, C, k};
       const int cj = S.code(j);
       if (cj == 0 || S.code(j + 1) == 0) continue;
       const FmPiece P = make_piece(S, j, cj);
@@ -252,8 +287,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
         const double ph = (acc + shift) - c;
         const long long t = tb + u;
         if (t >= t0 && t < t1) {
-          X1[(size_t)k * TBS + (int)(t - t0)] = ph;
-          X2[(size_t)k * TBS + (int)(t - t0)] = prev;
+          X1[(size_t)k * TP + (int)(t - t0)] = ph;
+          X2[(size_t)k * TP + (int)(t - t0)] = prev;
         }
         prev = ph;
       }
@@ -272,7 +307,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
     if (i >= A.No_ti) { i = A.No_ti - 1; r = (int)(t - (long long)i * D); }  // beyond the last instant
     past = (i == A.No_ti - 1) && (r > 0);
     for (int k = g; k < K; k += G) {
-      Slot S{A, k};
+      Slot S{A, C, k};
       double amv = 0.0, phv = 0.0, fnext = 0.0;
       const int ci = S.code(i);
       if (!past && r > 0) {
@@ -281,7 +316,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
           const double x0 = (double)i * (double)D, x1 = (double)(i + 1) * (double)D;
           const double a0v = S.am(i), a1v = S.am(i + 1);
           amv = ((a1v - a0v) / (x1 - x0)) * ((double)t - x0) + a0v;
-          const double pr = X1[(size_t)k * TBS + s], pm = X2[(size_t)k * TBS + s];
+          const double pr = X1[(size_t)k * TP + s], pm = X2[(size_t)k * TP + s];
           phv = pr;
           fnext = A.fs / (2.0 * M_PI) * unwrap_diff(pr - pm);
         }
@@ -293,7 +328,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
             phv = S.ph(i);  // isolated accepted instant: frame-centre values stay as written
           } else {
             double pD = 0.0, pDm1 = 0.0;
-            if (prev) { pD = X1[(size_t)k * TBS + s]; pDm1 = X2[(size_t)k * TBS + s]; }
+            if (prev) { pD = X1[(size_t)k * TP + s]; pDm1 = X2[(size_t)k * TP + s]; }
             if (next) {
               const double p0 = X3[(size_t)k * NK + (int)((t - tk0) / D)];
               const double w0 = (2.0 * M_PI / A.fs) * p0;
@@ -311,22 +346,23 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
       }
       A.am_out[(size_t)k * A.L + t] = amv;
       A.fm_out[(size_t)k * A.L + t] = fnext;
-      X1[(size_t)k * TBS + s] = (amv != 0.0) ? amv * cos(phv) : 0.0;   // same thread read this cell above
+      X1[(size_t)k * TP + s] = (amv != 0.0) ? amv * cos(phv) : 0.0;   // same thread read this cell above
     }
   }
   __syncthreads();
   double dsum = 0.0, dsq = 0.0;
   if (tid < TBS && live) {
     double synth = 0.0;
-    for (int k = 0; k < K; ++k) synth += X1[(size_t)k * TBS + s];
+    for (int k = 0; k < K; ++k) synth += X1[(size_t)k * TP + s];
     // a0: not-a-knot spline through every instant, extrapolated past the last one (functions.py:340)
     int ia = i;
     if (ia > A.No_ti - 2) ia = A.No_ti - 2;
     const int ld = K + 1;
     const size_t RS = 3 * (size_t)K + 1;
-    double a0v = spline_piece(A.records[(size_t)ia * RS + RS - 1], A.records[(size_t)(ia + 1) * RS + RS - 1],
-                              A.mom[(size_t)ia * ld + K],
-                              A.mom[(size_t)(ia + 1) * ld + K], (double)(t - (long long)ia * D), (double)D);
+    Slot S0{A, C, K};   // column K of mom = the a0 spline; its knots are the last record column
+    (void)ld;
+    double a0v = spline_piece(S0.recv(ia, (int)RS - 1), S0.recv(ia + 1, (int)RS - 1), S0.mom(ia), S0.mom(ia + 1),
+                              (double)(t - (long long)ia * D), (double)D);
     const double sh = a0v + 2.0 * synth;
     A.s_hat[t] = sh;
     if (t >= A.s_lo && t < A.s_hi) {
@@ -426,12 +462,13 @@ extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t
 }
 
 // samples per block of eaqhm_eval_kernel: the largest of 64/32/16 whose LDS tables fit
-static int eval_block_samples(int Kmax, int step, size_t* lds_bytes, int* nk) {
+static int eval_block_samples(int Kmax, int step, size_t* lds_bytes, int* nk, int* nr) {
   for (int tbs = 64; tbs >= 16; tbs >>= 1) {
-    const int NK = tbs / step + 2;
-    const size_t bytes = (((size_t)step + 2) & ~(size_t)1) * 8 + ((size_t)2 * Kmax * tbs + (size_t)Kmax * NK) * 8;
-    if (bytes <= 72 * 1024 || tbs == 16) {
-      *lds_bytes = bytes; *nk = NK;
+    const int NK = tbs / step + 2, NR = tbs / step + 5;   // staged instants: intervals of the block, one before, two after
+    const size_t bytes = (((size_t)step + 2) & ~(size_t)1) * 8 + ((size_t)2 * Kmax * (tbs + 1) + (size_t)Kmax * NK) * 8 +
+                         (size_t)NR * ((3 * (size_t)Kmax + 1) + (Kmax + 1)) * 8 + (((size_t)NR * Kmax + 7) & ~(size_t)7);
+    if (bytes <= 78 * 1024 || tbs == 16) {
+      *lds_bytes = bytes; *nk = NK; *nr = NR;
       return tbs;
     }
   }
@@ -457,12 +494,12 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   EvalArgs A{records, code, mom, No_ti, Kmax, step, fs, (long long)L, (long long)t_lo, (long long)t_hi,
              (long long)s_lo, (long long)s_hi, target, am_out, fm_out, ph_knot, s_hat, partials};
   size_t lds_bytes = 0;
-  int NK = 0;
-  const int TBS = eval_block_samples(Kmax, step, &lds_bytes, &NK);
+  int NK = 0, NR = 0;
+  const int TBS = eval_block_samples(Kmax, step, &lds_bytes, &NK, &NR);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: Kmax too large for the LDS tables");
   const long long nblocks = (t_hi - t_lo + TBS - 1) / TBS;
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK);
+  hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK, NR);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, 256 / TBS,
                      (double)(s_hi - s_lo), std_det, sums_out);
