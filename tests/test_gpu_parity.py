@@ -228,9 +228,16 @@ def test_voiced_only_option(amd):
 
 # ----------------------------------------------------------------------------- against the oracle
 @pytest.mark.parametrize("params", [dict(step=15, pitchPeriods=3, analysisWindow=32, partials=0),
-                                    dict(step=10, pitchPeriods=4, analysisWindow=50, partials=20)])
+                                    dict(step=10, pitchPeriods=4, analysisWindow=50, partials=20),
+                                    dict(step=15, pitchPeriods=3, analysisWindow=32, partials=0, f0scale=0.62)])
 def test_against_oracle_seeded_signal(amd, params):
-    """Same seeded synthetic input through the HIP path and the oracle, non-default parameters too."""
+    """Same seeded synthetic input through the HIP path and the oracle, non-default parameters too.  The third
+    case hands both a pitch track at 0.62 of the true pitch (105-167 Hz, a male-voice frame geometry: 46-74
+    harmonics, windows up to ~460 samples), so one launch mixes frames of the register-resident kernel with
+    frames of the large-frame kernel."""
+    params = dict(params)
+    f0scale = params.pop("f0scale", 1.0)
+    f0min = 160 if f0scale == 1.0 else 70
     import eaqhm_oracle as O
     from eaqhm_amd import prologue
     from eaqhm_amd.engine import DeviceAnalysis, FramePlan
@@ -238,30 +245,35 @@ def test_against_oracle_seeded_signal(amd, params):
     fs = 16000
     s = synth_speech_int16(0.9, fs) / 32768.0
     t = np.arange(0, len(s) / fs, 0.001)
-    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    f0 = f0scale * (220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t))
     track = np.column_stack([t, f0, np.ones_like(t)])
     grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     ti5 = np.array([f.ti for f in frames])
     sp = np.array([float(f.isSpeech) for f in frames])
     vo = np.array([float(f.isVoiced) for f in frames])
-    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=160, maxAdpt=2, step=params["step"],
+    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=f0min, maxAdpt=2, step=params["step"],
                     pitchPeriods=params["pitchPeriods"], analysisWindow=params["analysisWindow"],
                     partials=params["partials"])
     prologue.apply_full_waveform(frames, len(s), params["analysisWindow"] * params["step"])
     plan = FramePlan(len(s), fs, grid, frames, fstep, params["step"], params["pitchPeriods"],
                      params["analysisWindow"], params["partials"])
-    eng = DeviceAnalysis(s, s, plan, 160, 2)
+    eng = DeviceAnalysis(s, s, plan, f0min, 2)
     eng.run()
     fin = eng.final_arrays()
+    if f0scale != 1.0:
+        nt = (2 * (2 * plan.frame_K + 1) + 1 + 15) // 16
+        assert (nt <= 13).any() and (nt > 13).any()      # both LS kernels take part
     assert np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
-    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9
+    # the mis-scaled pitch puts every other basis column between true partials: a less well conditioned fit
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= (1e-9 if f0scale == 1.0 else 5e-8)
     m = ref["am"] != 0
     assert np.mean((fin["am"] != 0) == m) >= 0.999
     both = m & (fin["am"] != 0)
-    assert np.abs(fin["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
-    assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
-    assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= TOL_PH_RAD
+    loose = 1.0 if f0scale == 1.0 else 10.0   # observed there: amplitudes 1.6e-8 of the maximum
+    assert np.abs(fin["am"][both] - ref["am"][both]).max() <= loose * TOL_AM_REL * ref["am"].max()
+    assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= loose * TOL_FM_HZ
+    assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= loose * TOL_PH_RAD
 
 
 def test_entry_point_with_own_swipe(amd, sa19_golden):
