@@ -337,6 +337,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       STAMP(12);
       __syncthreads();
       STAMP(1);
+      const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;   // sample pairs in this chunk
+      const int ksl = (pcs + 1) >> 1;                             // k-steps (4 rows each) that hold samples
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
         if (!live[sl]) continue;
@@ -347,6 +349,26 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
         const int sw0 = lcol + (lq >> 1);
         asm volatile("" : "+v"(rb));   // keep the address arithmetic inside the loop (hoisted, it spills)
         const int plane = TS * ldx_max;
+        if (ksl < 8) {   // last chunk of the window: only the k-steps that hold samples (the other rows are zero)
+#pragma clang loop unroll(disable)
+          for (int ks = 0; ks < ksl; ++ks) {
+            const int sw = (sw0 + 2 * ks) & 15;
+            const double aR = Xre[rb + ca + sw], aI = Xre[rb + ca + sw + plane];
+            const double bR = Xre[rb + cb + sw], bI = Xre[rb + cb + sw + plane];
+            rb += 4 * ldx;
+            if constexpr (M3) {
+              accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
+              acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl], 0, 0, 0);
+              accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI - bR, accI[sl], 0, 0, 0);
+            } else {
+              accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
+              accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
+              accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
+              accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
+            }
+          }
+          continue;
+        }
         double aR, aI, bR, bI;
         {
           const int sw = sw0 & 15;
