@@ -161,31 +161,33 @@ __device__ inline double spline_piece(double y0, double y1, double m0, double m1
   return v * y0 + u * y1 + (h * h / 6.0) * ((v * v * v - v) * m0 + (u * u * u - u) * m1);
 }
 
-// fm_recon on the interval (i, i+1), both ends accepted, r in [0, step]
+// fm_recon on the interval (i, i+1), both ends accepted, r in [0, step].  Evaluated 2(step+1) times per interval,
+// so everything that does not depend on r is prepared once: no division and no array indexing per sample (a
+// wave that holds a single short-run interval runs both branches for all of its lanes).
 struct FmPiece {
   int kind;  // 2: spline piece, 3: single cubic through 4 points (short run, functions.py:368-371)
-  double y0, y1, m0, m1, h;
-  double px[4], py[4], x0;  // Lagrange nodes for the short-run case
+  double y0, y1, m0, m1, hinv, h2_6;
+  double p0, p1, p2, p3, w0, w1, w2, w3, x0;  // nodes and weights y_p / prod_{q != p}(x_p - x_q) of the short-run cubic
   __device__ double operator()(int r) const {
-    if (kind == 2) return spline_piece(y0, y1, m0, m1, (double)r, h);
-    double x = x0 + (double)r, acc = 0.0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      double l = py[p];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q != p) l *= (x - px[q]) / (px[p] - px[q]);
-      acc += l;
+    if (kind == 2) {
+      const double u = (double)r * hinv, v = 1.0 - u;
+      return v * y0 + u * y1 + h2_6 * ((v * v * v - v) * m0 + (u * u * u - u) * m1);
     }
-    return acc;
+    const double x = x0 + (double)r;
+    const double d0 = x - p0, d1 = x - p1, d2 = x - p2, d3 = x - p3;
+    return ((w0 * d1) * (d2 * d3) + (w1 * d0) * (d2 * d3)) + ((w2 * d3) * (d0 * d1) + (w3 * d2) * (d0 * d1));
   }
 };
 
 __device__ inline FmPiece make_piece(const Slot& S, int i, int ci) {
   FmPiece P;
   const int step = S.A.step;
-  P.h = (double)step;
-  P.x0 = (double)i * P.h;
+  const double h = (double)step;
+  P.hinv = 1.0 / h;
+  P.h2_6 = h * h / 6.0;
+  P.x0 = (double)i * h;
+  P.y0 = P.y1 = P.m0 = P.m1 = 0.0;
+  P.p0 = 0.0; P.p1 = 1.0; P.p2 = 2.0; P.p3 = 3.0; P.w0 = P.w1 = P.w2 = P.w3 = 0.0;
   if (ci == 2) {
     P.kind = 2;
     P.y0 = S.fm(i); P.y1 = S.fm(i + 1); P.m0 = S.mom(i); P.m1 = S.mom(i + 1);
@@ -194,14 +196,19 @@ __device__ inline FmPiece make_piece(const Slot& S, int i, int ci) {
     const int m = (ci - 16) >> 2, pos = (ci - 16) & 3;
     const int rs = i - pos;
     const int npad = 4 - m;  // knots at samples 0, step, ... carry whatever fm_recon holds there
-    for (int p = 0; p < npad; ++p) {
-      P.px[p] = (double)(p * step);
-      P.py[p] = (p < S.A.No_ti && S.code(p) != 0) ? S.fm(p) : 0.0;
+    double px[4], py[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool pad = p < npad;
+      const int row = pad ? p : (rs + p - npad);
+      px[p] = pad ? (double)(p * step) : (double)row * h;
+      py[p] = (pad && !(p < S.A.No_ti && S.code(p) != 0)) ? 0.0 : S.fm(row);
     }
-    for (int q = 0; q < m; ++q) {
-      P.px[npad + q] = (double)(rs + q) * P.h;
-      P.py[npad + q] = S.fm(rs + q);
-    }
+    P.p0 = px[0]; P.p1 = px[1]; P.p2 = px[2]; P.p3 = px[3];
+    P.w0 = py[0] / ((px[0] - px[1]) * (px[0] - px[2]) * (px[0] - px[3]));
+    P.w1 = py[1] / ((px[1] - px[0]) * (px[1] - px[2]) * (px[1] - px[3]));
+    P.w2 = py[2] / ((px[2] - px[0]) * (px[2] - px[1]) * (px[2] - px[3]));
+    P.w3 = py[3] / ((px[3] - px[0]) * (px[3] - px[1]) * (px[3] - px[2]));
   }
   return P;
 }
