@@ -53,20 +53,19 @@ __device__ double inner_moment(const SplineCol& C, const double* lp, int i, int 
   const int dhi = (B >= SPL_BIG) ? SPL_W : min(SPL_W, B - 2);
   const double lam2 = lp[2];
   const double np1 = (A >= SPL_BIG || B >= SPL_BIG) ? 0.0 : lam_pow(lp, 2 * (A + B - 2));  // lam^(2(n+1))
-  const double den = (1.0 - lam2) * (1.0 - np1);
+  const double iden = 1.0 / ((1.0 - lam2) * (1.0 - np1)), ih2 = 6.0 / C.h2;   // no division inside the 69-term loop
   double ym = C.y(i + dlo - 1), y0 = C.y(i + dlo), yp;
   double acc = 0.0;
   for (int d = dlo; d <= dhi; ++d) {
     yp = C.y(i + d + 1);
-    const double h2 = C.h2;
-    double rhs = 6.0 * ((ym - 2.0 * y0) + yp) / h2;
+    double rhs = ((ym - 2.0 * y0) + yp) * ih2;
     if (A < SPL_BIG && A + d == 2) rhs -= C.d2(i + d - 1) / 6.0;   // first inner row: - M_1
     if (B < SPL_BIG && B - d == 2) rhs -= C.d2(i + d + 1) / 6.0;   // last inner row:  - M_{m-2}
     const int ad = d < 0 ? -d : d;
     // min(i', j') = A-1+min(d,0);  n+1-max(i', j') = B-1-max(d,0)
     const double fa = (A >= SPL_BIG) ? 1.0 : 1.0 - lam_pow(lp, 2 * (A - 1 + (d < 0 ? d : 0)));
     const double fb = (B >= SPL_BIG) ? 1.0 : 1.0 - lam_pow(lp, 2 * (B - 1 - (d > 0 ? d : 0)));
-    double w = lam_pow(lp, ad + 1) * fa * fb / den;
+    const double w = (lam_pow(lp, ad + 1) * fa) * (fb * iden);
     acc += (ad & 1) ? -w * rhs : w * rhs;
     ym = y0; y0 = yp;
   }
@@ -108,17 +107,28 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const doub
     } else {
       cd = 2;
       const int A = kl ? dl : SPL_BIG, B = kr ? dr : SPL_BIG;
-      if (A == 0) {
-        M = 2.0 * inner_moment(C, lp, i + 1, 1, B - 1) - inner_moment(C, lp, i + 2, 2, B - 2);
-      } else if (B == 0) {
-        M = 2.0 * inner_moment(C, lp, i - 1, A - 1, 1) - inner_moment(C, lp, i - 2, A - 2, 2);
-      } else {
-        M = inner_moment(C, lp, i, A, B);
-      }
+      // the first / last knot of a run takes 2 M_1 - M_2 from its neighbours' moments: eaqhm_spline_edge_kernel
+      // (computing them here would make every wave that holds one edge knot run the 69-term sum three times)
+      if (A != 0 && B != 0) M = inner_moment(C, lp, i, A, B);
     }
   }
   mom[(size_t)i * ld + k] = M;
   if (k < Kmax) code[(size_t)i * Kmax + k] = cd;
+}
+
+// not-a-knot end conditions: M_0 = 2 M_1 - M_2 and M_{m-1} = 2 M_{m-2} - M_{m-3} for runs of m >= 4 knots (code 2)
+extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_edge_kernel(const unsigned char* __restrict__ code, int No_ti,
+                                                                           int Kmax, double* __restrict__ mom) {
+  const int ld = Kmax + 1;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)No_ti * ld) return;
+  const int i = (int)(idx / ld), k = (int)(idx - (long long)i * ld);
+  auto acc = [&](int q) { return q >= 0 && q < No_ti && (k == Kmax || code[(size_t)q * Kmax + k] != 0); };
+  if (!(k == Kmax || code[(size_t)i * Kmax + k] == 2)) return;
+  const bool first = !acc(i - 1), last = !acc(i + 1);
+  if (first == last) return;   // inner knot (or isolated: not code 2)
+  const int s1 = first ? 1 : -1;
+  mom[(size_t)i * ld + k] = 2.0 * mom[(size_t)(i + s1) * ld + k] - mom[(size_t)(i + 2 * s1) * ld + k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,6 +474,9 @@ extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t
   const long long cells = (long long)No_ti * (Kmax + 1);
   hipLaunchKernelGGL(eaqhm_spline_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, records, No_ti,
                      Kmax, step, code, mom);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(eaqhm_spline_edge_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, code, No_ti,
+                     Kmax, mom);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }
