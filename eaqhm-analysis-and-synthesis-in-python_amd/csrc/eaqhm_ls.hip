@@ -176,21 +176,30 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 // adaptation >= 1 frame set-up (functions.py:202-213): active slots + empty-row seeding flags
-extern "C" __global__ void eaqhm_frame_prep_kernel(const double* fm_cur, long long L, int Kmax, const int* frame_c,
-                                                   int n_frames, int* ncol, int* cols, unsigned char* seeded,
-                                                   int* any_seed) {
-  int f = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per frame: lanes test 64 slots at a time, the ballot gives count and compacted positions.
+extern "C" __global__ void __launch_bounds__(256) eaqhm_frame_prep_kernel(const double* fm_cur, long long L, int Kmax,
+                                                                          const int* frame_c, int n_frames, int* ncol,
+                                                                          int* cols, unsigned char* seeded, int* any_seed) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (f >= n_frames) return;
-  int c = frame_c[f], n = 0;
-  for (int k = 0; k < Kmax; ++k)
-    if (fm_cur[(size_t)k * L + c] != 0.0) cols[(size_t)f * Kmax + n++] = k;
-  if (n == 0) {
-    seeded[c] = 1;
-    cols[(size_t)f * Kmax] = 0;
-    n = 1;
-    atomicOr(any_seed, 1);
+  const int c = frame_c[f];
+  int n = 0;
+  for (int k0 = 0; k0 < Kmax; k0 += 64) {
+    const int k = k0 + lane;
+    const bool nz = (k < Kmax) && (fm_cur[(size_t)k * L + c] != 0.0);
+    const unsigned long long m = __ballot(nz);
+    if (nz) cols[(size_t)f * Kmax + n + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    n += __popcll(m);
   }
-  ncol[f] = n;
+  if (lane == 0) {
+    if (n == 0) {
+      seeded[c] = 1;
+      cols[(size_t)f * Kmax] = 0;
+      n = 1;
+      atomicOr(any_seed, 1);
+    }
+    ncol[f] = n;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -273,7 +282,7 @@ extern "C" int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L,
   HIP_TRY(ctx, hipMemsetAsync(seeded, 0, (size_t)L, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(any_seed, 0, sizeof(int32_t), ctx->stream));
   if (n_frames == 0) return EAQHM_OK;
-  hipLaunchKernelGGL(eaqhm_frame_prep_kernel, dim3((n_frames + 127) / 128), dim3(128), 0, ctx->stream, fm_cur,
+  hipLaunchKernelGGL(eaqhm_frame_prep_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, ctx->stream, fm_cur,
                      (long long)L, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
