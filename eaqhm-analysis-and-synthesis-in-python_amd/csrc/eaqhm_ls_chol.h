@@ -15,14 +15,19 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // forward elimination on [L | I]), three LDS reads, one reciprocal, one complex multiply-add, one barrier.
 //   D  [16][16] complex (interleaved), row-major, lower triangle used;  Z likewise (starts as identity)
 //   outputs: Wt planes hold (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j];  Ld planes hold L[i][j] at [i*TL_LD + j]
+// identity into Z, to be called before the barrier that publishes the diagonal tile in D
+__device__ inline void diag_init(double* Z, int tid) {
+  const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;
+  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
+}
+
 __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
   // 2x2 block pivots: seven elimination steps instead of fifteen.  With P = [[p, conj(q)], [q, r]] the pivot block
   // of columns (j, j+1) and a = D[i][j..j+1], b = D[k][j..j+1]:   D[i][k] -= a P^-1 b^H   (i >= k >= j+2), and
   // the rows of the inverse below the block follow the same elimination on [L | I].  Columns / rows inside a
   // block stay raw until the final scaling, which applies the block's own 2x2 Cholesky factor.
+  // (Z must hold the identity and D the tile when the workgroup arrives here: diag_init + the caller's barrier)
   const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
-  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
-  __syncthreads();
 #pragma clang loop unroll(disable)
   for (int j = 0; j < 14; j += 2) {
     const bool work = (g == 0) ? (k >= j + 2 && i >= k) : (i >= j + 2 && k <= j + 1);
@@ -186,6 +191,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = p3[0][r];
       }
     }
+    diag_init(Zc, tid);
     __syncthreads();
     diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid);   // ends with a barrier
     for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous

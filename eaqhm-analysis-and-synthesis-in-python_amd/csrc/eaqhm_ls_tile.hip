@@ -438,7 +438,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
               }
             }
         }
-        __syncthreads();  // (A) diagonal tile published
+        diag_init(Zc, tid);
+        __syncthreads();  // (A) diagonal tile published, inverse initialised
         STAMP(6);
         diag_coop(Dc, Zc, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, tid);  // ends with a barrier
         STAMP(10);
