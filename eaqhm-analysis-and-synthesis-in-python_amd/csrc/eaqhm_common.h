@@ -16,7 +16,7 @@ struct eaqhm_ctx {
   int n_cu = 0;
   int lds_bytes = 0;
   int clock_khz = 0;
-  int ls_variant = 3;  // 1: VALU Gramian (any size), 2: MFMA Gramian + scratch Cholesky, 3: all-on-chip tiles (+2 for big frames)
+  int ls_variant = 3;  // 1: VALU Gramian (any size), 2: MFMA Gramian + tile Cholesky through memory, 3: all-on-chip tiles (+2 for big frames)
   int dbg_keep = 0;    // 1: in-kernel phase stamps on, accumulated across launches (diagnostics only)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;

@@ -5,12 +5,14 @@
 //                         (functions.py:350-362) and the not-a-knot cubic second derivatives on their knots
 //                         (functions.py:340, :367; interp1d(kind=3)) through the closed-form inverse of the
 //                         (1,4,1) system — a local 69-term sum instead of a sequential tridiagonal sweep.
-//   eaqhm_eval_kernel     one thread per sample, loop over slots: linear am (functions.py:364), cubic fm
-//                         (:367-371 incl. the padded <4-knot case), phase by frequency integration with the
-//                         sine-bump correction (functions.py:537-575), next-iteration frequency from the
-//                         unwrapped phase (:375), synthesis a0 + 2*sum am*cos(ph) (:385) and the partial
-//                         sums of the reconstruction error (:388).  Every (slot, sample) cell of the two
-//                         dense outputs is written, so no memset is needed between adaptations.
+//   eaqhm_spline_edge_kernel  not-a-knot end conditions of every run from its neighbours' moments.
+//   eaqhm_eval_kernel     one block per 16-64 samples x all slots: each knot interval is integrated once (linear
+//                         am, functions.py:364; cubic fm, :367-371 incl. the padded <4-knot case; phase by
+//                         frequency integration with the sine-bump correction, :537-575) into LDS tables; then
+//                         per (sample, slot) the next-iteration frequency from the unwrapped phase (:375) and
+//                         am*cos(ph); per sample the synthesis a0 + 2*sum am*cos(ph) (:385) and the partial sums
+//                         of the reconstruction error (:388).  Every (slot, sample) cell of the two dense
+//                         outputs is written, so no memset is needed between adaptations.
 //   eaqhm_srer_kernel     deterministic final reduction + SRER in dB.
 //
 // Bandwidth-type stage: per adaptation it reads (1+3*Kmax)*8*No_ti bytes of records and writes

@@ -50,7 +50,7 @@ int eaqhm_set_stream(eaqhm_ctx* ctx, void* hip_stream);
 int eaqhm_sync(eaqhm_ctx* ctx);
 const char* eaqhm_last_error(eaqhm_ctx* ctx);
 /* tuning knobs (for A/B measurements; defaults are the fastest validated choice)
- *   EAQHM_OPT_LS_VARIANT: 1 = VALU Gramian + scratch Cholesky (any size), 2 = MFMA Gramian + scratch Cholesky,
+ *   EAQHM_OPT_LS_VARIANT: 1 = VALU Gramian + column Cholesky through scratch (any size), 2 = MFMA Gramian + tile Cholesky through memory,
  *                         3 = Gramian and tile Cholesky on chip for frames of <= 6 column blocks, 2 for the rest
  *                             (default) */
 #define EAQHM_OPT_LS_VARIANT 1
