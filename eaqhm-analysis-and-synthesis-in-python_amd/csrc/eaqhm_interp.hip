@@ -372,7 +372,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
   double dsum = 0.0, dsq = 0.0;
   if (tid < TBS && live) {
     double synth = 0.0;
-    for (int k = 0; k < K; ++k) synth += X1[(size_t)k * TP + s];
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) synth += X1[(size_t)k * TP + s];   // slot order; the loads of eight slots in flight
     // a0: not-a-knot spline through every instant, extrapolated past the last one (functions.py:340)
     int ia = i;
     if (ia > A.No_ti - 2) ia = A.No_ti - 2;
