@@ -75,7 +75,7 @@ __device__ double inner_moment(const SplineCol& C, const double* lp, int i, int 
 }
 
 extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const double* __restrict__ records, int No_ti,
-                                                                      int Kmax, int step,
+                                                                      int i0, int ni, int Kmax, int step,
                                                                       unsigned char* __restrict__ code,
                                                                       double* __restrict__ mom) {
   __shared__ double lp[80];
@@ -83,8 +83,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const doub
   __syncthreads();
   const int ld = Kmax + 1;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)No_ti * ld) return;
-  const int i = (int)(idx / ld), k = (int)(idx - (long long)i * ld);
+  if (idx >= (long long)ni * ld) return;
+  const int i = i0 + (int)(idx / ld), k = (int)(idx % ld);
   SplineCol C;
   C.rec = records; C.RS = 3 * Kmax + 1; C.No_ti = No_ti; C.all_acc = (k == Kmax);
   C.off_y = (k == Kmax) ? 3 * Kmax : Kmax + k;
@@ -120,11 +120,11 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_kernel(const doub
 
 // not-a-knot end conditions: M_0 = 2 M_1 - M_2 and M_{m-1} = 2 M_{m-2} - M_{m-3} for runs of m >= 4 knots (code 2)
 extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_edge_kernel(const unsigned char* __restrict__ code, int No_ti,
-                                                                           int Kmax, double* __restrict__ mom) {
+                                                                           int i0, int ni, int Kmax, double* __restrict__ mom) {
   const int ld = Kmax + 1;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)No_ti * ld) return;
-  const int i = (int)(idx / ld), k = (int)(idx - (long long)i * ld);
+  if (idx >= (long long)ni * ld) return;
+  const int i = i0 + (int)(idx / ld), k = (int)(idx % ld);
   auto acc = [&](int q) { return q >= 0 && q < No_ti && (k == Kmax || code[(size_t)q * Kmax + k] != 0); };
   if (!(k == Kmax || code[(size_t)i * Kmax + k] == 2)) return;
   const bool first = !acc(i - 1), last = !acc(i + 1);
@@ -468,20 +468,33 @@ extern "C" __global__ void eaqhm_phase_integrate_kernel(const double* __restrict
 
 using namespace eaqhm;
 
-extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti,
-                                  int32_t Kmax, int32_t step, uint8_t* code, double* mom) {
+extern "C" int eaqhm_spline_solve_range(eaqhm_ctx* ctx, const double* records, int32_t No_ti, int32_t Kmax, int32_t step,
+                                        int32_t i_lo, int32_t i_hi, uint8_t* code, double* mom) {
   if (!ctx) return EAQHM_EINVAL;
-  if (!records || !code || !mom || Kmax <= 0 || step <= 0)
+  if (!records || !code || !mom || Kmax <= 0 || step <= 0 || i_lo < 0 || i_hi > No_ti || i_lo >= i_hi)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: bad argument");
   if (No_ti < 4) return ctx->fail(EAQHM_EINVAL, "eaqhm_spline_solve: need at least 4 analysis instants (interp1d kind=3)");
-  const long long cells = (long long)No_ti * (Kmax + 1);
-  hipLaunchKernelGGL(eaqhm_spline_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, records, No_ti,
-                     Kmax, step, code, mom);
+  const int ld = Kmax + 1;
+  auto blocks = [&](int n) { return dim3((unsigned)(((long long)n * ld + 255) / 256)); };
+  // moments two instants beyond the range feed the end conditions of runs that start / stop inside it
+  const int a = (i_lo - 2 > 0) ? i_lo - 2 : 0, b = (i_hi + 2 < No_ti) ? i_hi + 2 : No_ti;
+  hipLaunchKernelGGL(eaqhm_spline_kernel, blocks(b - a), dim3(256), 0, ctx->stream, records, No_ti, a, b - a, Kmax, step,
+                     code, mom);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(eaqhm_spline_edge_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, code, No_ti,
-                     Kmax, mom);
+  if (a > 0) {   // the padded <4-knot case looks at the run codes of instants 0..3 wherever it is evaluated
+    const int n0 = (a < 4) ? a : 4;
+    hipLaunchKernelGGL(eaqhm_spline_kernel, blocks(n0), dim3(256), 0, ctx->stream, records, No_ti, 0, n0, Kmax, step, code, mom);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(eaqhm_spline_edge_kernel, blocks(i_hi - i_lo), dim3(256), 0, ctx->stream, code, No_ti, i_lo,
+                     i_hi - i_lo, Kmax, mom);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
+}
+
+extern "C" int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti,
+                                  int32_t Kmax, int32_t step, uint8_t* code, double* mom) {
+  return eaqhm_spline_solve_range(ctx, records, No_ti, Kmax, step, 0, No_ti, code, mom);
 }
 
 // samples per block of eaqhm_eval_kernel: the largest of 64/32/16 whose LDS tables fit

@@ -4,7 +4,7 @@ instants of each adaptation sharded over the ranks (one process per GPU).
 Per adaptation a rank runs
     [frame_prep] -> ls_batch            its own contiguous range of analysis instants
     all-gather of the frame-centre records (RCCL over xGMI; skipped when world_size == 1)
-    spline_solve                        every rank, all instants (small, deterministic)
+    spline_solve                        every rank, the instants its own time range looks at
     eval_synth                          its own time range plus a halo of max(wl) samples, so the dense
                                         tracks its frames will window in the next adaptation are local
     all-reduce of the two error sums    (16 bytes; skipped when world_size == 1)
@@ -124,6 +124,9 @@ class DeviceAnalysis:
         self.s_lo, self.s_hi = bound(sh.rank), bound(sh.rank + 1)
         self.t_lo = max(0, self.s_lo - p.wl_max)
         self.t_hi = min(L, self.s_hi + p.wl_max)
+        # instants whose run codes / spline moments the evaluation of [t_lo, t_hi) looks at
+        self.sp_lo = max(0, (max(self.t_lo, 1) - 1) // p.step - 2)
+        self.sp_hi = max(self.sp_lo + 1, min(T, (max(self.t_hi, 1) - 1) // p.step + 4))
 
         def dev_i32(a):
             return torch.as_tensor(np.ascontiguousarray(a[lo:hi]), dtype=i32, device=dev)
@@ -201,7 +204,7 @@ class DeviceAnalysis:
         p, c, sh = self.plan, self.ctx, self.shard
         sh.all_gather_rows(self.records[0], p.No_ti)
         e0 = self._mark()
-        c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom)
+        c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom, self.sp_lo, self.sp_hi)
         if self.s_hi > self.s_lo:
             c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
                          self.t_lo, self.t_hi, self.s_lo, self.s_hi, self.target, self.std_det, self.am_cur,

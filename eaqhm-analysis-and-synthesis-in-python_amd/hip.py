@@ -28,6 +28,7 @@ SYMBOLS = (
     ("eaqhm_ls_explicit", C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _P, _F64, _P, _P]),
     ("eaqhm_phase_integrate", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     ("eaqhm_spline_solve", C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    ("eaqhm_spline_solve_range", C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     ("eaqhm_eval_synth", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F64, _I64, _I64, _I64, _I64, _I64, _P, _F64,
                                     _P, _P, _P, _P, _P, _P]),
     ("eaqhm_eval_partials_len", _I64, [_I64, _I64, _I32]),
@@ -150,8 +151,10 @@ class Context:
     def phase_integrate(self, omega, ph, knots, n_knots, first, last, out):
         self._ck(self.lib.eaqhm_phase_integrate(self.h, _ptr(omega), _ptr(ph), _ptr(knots), n_knots, first, last, _ptr(out)))
 
-    def spline_solve(self, records, No_ti, Kmax, step, code, mom):
-        self._ck(self.lib.eaqhm_spline_solve(self.h, _ptr(records), No_ti, Kmax, step, _ptr(code), _ptr(mom)))
+    def spline_solve(self, records, No_ti, Kmax, step, code, mom, i_lo=0, i_hi=None):
+        i_hi = No_ti if i_hi is None else i_hi
+        self._ck(self.lib.eaqhm_spline_solve_range(self.h, _ptr(records), No_ti, Kmax, step, i_lo, i_hi, _ptr(code),
+                                                   _ptr(mom)))
 
     def eval_synth(self, records, code, mom, No_ti, Kmax, step, fs, L, t_lo, t_hi, s_lo, s_hi, target, std_det,
                    am_out, fm_out, ph_knot, s_hat, partials, sums_out):

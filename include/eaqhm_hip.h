@@ -124,6 +124,10 @@ int eaqhm_phase_integrate(eaqhm_ctx* ctx, const double* omega, const double* ph,
  *   mom[i][k]   double[No_ti][Kmax+1] second derivatives of the fm splines (column Kmax: the a0 spline) */
 int eaqhm_spline_solve(eaqhm_ctx* ctx, const double* records, int32_t No_ti, int32_t Kmax, int32_t step,
                        uint8_t* code, double* mom);
+/* the same for the instants [i_lo, i_hi) only (a rank that evaluates only its own time range: the moments are
+ * local sums, so the rest of `code` / `mom` is neither read nor written, except the run codes of instants 0..3) */
+int eaqhm_spline_solve_range(eaqhm_ctx* ctx, const double* records, int32_t No_ti, int32_t Kmax, int32_t step,
+                             int32_t i_lo, int32_t i_hi, uint8_t* code, double* mom);
 
 /* interpolation stage 2 + synthesis + SRER -----------------------------------------------------------
  * Replaces functions.py:364 (linear am), :367-371 (cubic fm, incl. the <4-knot padded case),

@@ -76,7 +76,7 @@ class OracleBackend:
             else:
                 row[Kmax + k] = fm[c, k] + (eta[ok] if f0 > f0min else 0.0)
 
-    def spline_solve(self, records, No_ti, Kmax, step, code, mom):
+    def spline_solve(self, records, No_ti, Kmax, step, code, mom, i_lo=0, i_hi=None):
         pass                                                      # folded into eval_synth below
 
     # ---- functions.py:337-388
