@@ -319,13 +319,16 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
     const size_t frame_bytes = (st_m > st_t ? st_m : st_t) * grid * sizeof(double);
     const int zchunks = (int)((L + 1023) >> 10);
     const size_t zloc_bytes = (((size_t)Kmax * L * sizeof(unsigned short)) + 255) & ~(size_t)255;
-    const size_t flag_bytes = zloc_bytes + ((((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255);
+    const size_t ztot_bytes = (((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255;
+    const size_t flag_bytes = zloc_bytes + ztot_bytes + (((size_t)zchunks + 255) & ~(size_t)255);
     const size_t cls_bytes = ((16 + (size_t)6 * n_frames) * sizeof(int) + 255) & ~(size_t)255;
     int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
     if (rc) return rc;
     B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes);
     B.ztot = (const int*)((char*)ctx->scratch + frame_bytes + zloc_bytes);
     B.zchunks = zchunks;
+    B.zflag = (unsigned char*)ctx->scratch + frame_bytes + zloc_bytes + ztot_bytes;
+    if (mode == 1) HIP_TRY(ctx, hipMemsetAsync(B.zflag, 0, (size_t)zchunks, ctx->stream));
     B.cls = (int*)((char*)ctx->scratch + frame_bytes + flag_bytes);
     HIP_TRY(ctx, hipMemsetAsync(B.cls, 0, 16 * sizeof(int), ctx->stream));
     int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
@@ -354,7 +357,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
   A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
   A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
-  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr; A.zloc = nullptr; A.ztot = nullptr; A.zchunks = 0; A.cls = nullptr;
+  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr; A.zloc = nullptr; A.ztot = nullptr; A.zchunks = 0; A.zflag = nullptr; A.cls = nullptr;
   size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

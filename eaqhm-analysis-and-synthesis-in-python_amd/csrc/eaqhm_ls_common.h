@@ -20,6 +20,7 @@ struct LsArgs {
   // zero counts of the frequency tracks (tile variant, mode 1; eaqhm_ls_zero_prefix_kernel): zloc[k][t] = zeros of
   // fm_cur[k] from the start of t's 1024-sample chunk up to t, ztot[k][chunk] = zeros of the whole chunk
   const unsigned short* zloc; const int* ztot; int zchunks;
+  unsigned char* zflag;   // [zchunks] chunks some frame window of this launch touches (only those are counted)
   // frames bucketed by size (tile variant): cls[0..5] counts, cls[8..13] cursors, cls[16 + c*n_frames + i] frame ids.
   // Classes 0-4 are the register budgets of eaqhm_ls_tile_kernel, class 5 is left to eaqhm_ls_mfma_kernel.
   int* cls;

@@ -581,6 +581,11 @@ __device__ inline int frame_class(int n) {
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArgs A) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
   const int cl = (f < A.n_frames) ? frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]) : -1;
+  if (A.mode == 1 && f < A.n_frames) {   // chunks of the zero counts this frame's window (and the sample before it) touches
+    const long long c = A.frame_c[f], wl = A.frame_wl[f];
+    const long long lo = (c - wl - 1 > 0) ? (c - wl - 1) : 0;
+    for (long long ch = lo >> 10; ch <= ((c + wl) >> 10); ++ch) A.zflag[ch] = 1;
+  }
   for (int c = 0; c < 6; ++c) {   // one atomic per wave and class, positions from the ballot
     const unsigned long long m = __ballot(cl == c);
     if (m == 0ull) continue;
@@ -594,10 +599,12 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArg
 // Zero counts of every frequency track, in chunks of 1024 samples (LsArgs::zloc / ztot): a frame then knows with two
 // look-ups per slot whether its window needs bridging, instead of scanning n windows of N samples.
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(const double* __restrict__ fm, long long L,
-                                                                              int zchunks, unsigned short* __restrict__ zloc,
+                                                                              int zchunks, const unsigned char* __restrict__ zflag,
+                                                                              unsigned short* __restrict__ zloc,
                                                                               int* __restrict__ ztot) {
   __shared__ int wsum[4];
   const int k = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!zflag[ch]) return;   // no frame of this launch (this rank) looks here
   const long long base = (long long)ch << 10;
   int run = 0;
   for (int p = 0; p < 4; ++p) {
@@ -670,7 +677,7 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
     hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(A.zchunks, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.L,
-                       A.zchunks, (unsigned short*)A.zloc, (int*)A.ztot);
+                       A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
