@@ -181,7 +181,11 @@ class DeviceAnalysis:
     def ls_stage(self, a):
         """Per-frame LS of adaptation `a` for this rank's frames -> rows of records[0]."""
         p, c = self.plan, self.ctx
-        self.records[0].zero_()
+        if self.shard.collective:          # the other ranks' rows arrive with the all-gather
+            ck = self.shard.chunk(p.No_ti)
+            self.records[0][self.shard.rank * ck:(self.shard.rank + 1) * ck].zero_()
+        else:
+            self.records[0].zero_()
         if self.nf == 0:
             return
         if a > 0:
