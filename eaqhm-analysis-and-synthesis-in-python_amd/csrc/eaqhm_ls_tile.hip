@@ -155,7 +155,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool spec = false;
   // ---- LDS carve-up: region U is the basis chunk (+ slot info) in the Gramian phase, tile storage afterwards
   double* U = lds;
   double* Xre = U;
@@ -225,7 +224,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     if (A.mode == 1) prepare_slots(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, f);
     STAMP(0);
 
-    // system tiles of this wave (compute waves only)
+    // system tiles of this wave
     constexpr bool M3 = (NS <= 5);   // register budget: a third accumulator per tile only for the smaller frames
     d4 accR[NS], accI[NS], acc3[M3 ? NS : 1];
     int tP[NS], tQ[NS];
@@ -236,7 +235,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       accI[sl] = (d4){0, 0, 0, 0};
       if (M3) acc3[sl] = (d4){0, 0, 0, 0};
       const int x = sl * TL_CW + wave;
-      live[sl] = (!spec) && (x < ntiles);
+      live[sl] = x < ntiles;
       int P = 0, Q = 0;
       sys_tile_of(live[sl] ? x : 0, P, Q);
       tP[sl] = P; tQ[sl] = Q;
@@ -409,7 +408,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
     }
 
     {
-      // ================= compute waves =================
       // ---- padding positions of the last tile row/column (beyond the signal) get an identity row/column
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
@@ -426,7 +424,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       }
       for (int jb = 0; jb < nt; ++jb) {
         const int xd = jb * (jb + 1) / 2 + jb;
-        if (wave == (xd % TL_CW)) {  // hand the diagonal tile to the specialist: Dt[row][col] = T[row][col]
+        if (wave == (xd % TL_CW)) {  // publish the diagonal tile: Dc[row][col] = T[row][col]
           const int sd = xd / TL_CW;
 #pragma unroll
           for (int sl = 0; sl < NS; ++sl)
