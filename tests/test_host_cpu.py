@@ -37,6 +37,11 @@ def test_no_cpu_fallback():
     with pytest.raises(eaqhm_amd.HipUnavailable):
         eaqhm_amd.eaQHMAnalysisAndSynthesis(os.path.join(GOLDEN, "SA19.WAV"), "female", printPrompts=False,
                                             pitch_track=g["swipe_track"])
+    with pytest.raises(eaqhm_amd.HipUnavailable):      # the batch entry fails the same way
+        eaqhm_amd.eaQHMAnalysisAndSynthesisBatch([os.path.join(GOLDEN, "SA19.WAV")], "female",
+                                                 pitch_tracks=[g["swipe_track"]])
+    with pytest.raises(ValueError):                    # ... after its own argument checks
+        eaqhm_amd.eaQHMAnalysisAndSynthesisBatch(["a.wav", "b.wav"], ["female"])
     pkg = os.path.join(ROOT, "eaqhm-analysis-and-synthesis-in-python_amd")
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
