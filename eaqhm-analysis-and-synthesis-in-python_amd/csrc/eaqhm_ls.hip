@@ -328,15 +328,19 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
     B.ztot = (const int*)((char*)ctx->scratch + frame_bytes + zloc_bytes);
     B.zchunks = zchunks;
     B.zflag = (unsigned char*)ctx->scratch + frame_bytes + zloc_bytes + ztot_bytes;
-    if (mode == 1) HIP_TRY(ctx, hipMemsetAsync(B.zflag, 0, (size_t)zchunks, ctx->stream));
+    {   // chunk flags and the class header right behind them: one clear for both
+      const size_t zflag_bytes = flag_bytes - zloc_bytes - ztot_bytes;
+      HIP_TRY(ctx, hipMemsetAsync(B.zflag, 0, zflag_bytes + 16 * sizeof(int), ctx->stream));
+    }
     B.cls = (int*)((char*)ctx->scratch + frame_bytes + flag_bytes);
-    HIP_TRY(ctx, hipMemsetAsync(B.cls, 0, 16 * sizeof(int), ctx->stream));
     int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
+    const bool tile_path = ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax);
+    if (!tile_path)   // the frame queue of the fallback kernel when it takes every frame
+      HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
     B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
     B.scratch = (double*)ctx->scratch;
     int min_nb = 0;
-    if (ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax)) {   // small frames: everything in registers/LDS; the rest falls through
+    if (tile_path) {   // small frames: everything in registers/LDS; the rest falls through
       B.scratch_stride = st_t; B.work_counter = counters + 2;
       rc = launch_ls_tile(ctx, B, grid);
       if (rc) return rc;

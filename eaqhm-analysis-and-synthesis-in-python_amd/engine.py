@@ -181,11 +181,9 @@ class DeviceAnalysis:
     def ls_stage(self, a):
         """Per-frame LS of adaptation `a` for this rank's frames -> rows of records[0]."""
         p, c = self.plan, self.ctx
-        if self.shard.collective:          # the other ranks' rows arrive with the all-gather
-            ck = self.shard.chunk(p.No_ti)
-            self.records[0][self.shard.rank * ck:(self.shard.rank + 1) * ck].zero_()
-        else:
-            self.records[0].zero_()
+        # No clearing of records[0]: every analysed instant's row is rewritten completely by its frame (the set of
+        # analysed instants never changes), the rows of the others are never written and stay zero from the
+        # allocation, and the rows of other ranks arrive with the all-gather.
         if self.nf == 0:
             return
         if a > 0:
