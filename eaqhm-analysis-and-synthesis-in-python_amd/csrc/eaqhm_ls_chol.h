@@ -127,9 +127,10 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
 // LDS by the whole workgroup (diag_coop) and the panel tiles are multiplied by the inverse (MFMA) and stored.
 // The right-hand side rides along as the last tile row, so the forward substitution is free; the back
 // substitution walks the tile columns from the stored factor.
-#define CH_MB 6          // tiles per wave and column: nt <= 8 * CH_MB
+#define CH_MB 6          // tiles per wave, column and register group
+#define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
-#define CH_LDS_DOUBLES (512 + 512 + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * 8 * CH_MB + 32)
+#define CH_LDS_DOUBLES (512 + 512 + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32)
 
 // T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
 __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, int nt, int Kc, int nbk,
@@ -144,85 +145,93 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
   double* LdI = LdR + TL_TILE;
   double* trb = LdI + TL_TILE + (size_t)wave * 2 * TL_TILE;   // this wave's transposition buffer
   double* zv = LdI + TL_TILE + 8 * 2 * TL_TILE;
-  double* xv = zv + 2 * 16 * 8 * CH_MB;
+  double* xv = zv + 2 * 16 * CH_NTMAX;
 
   for (int Q = 0; Q < nt; ++Q) {
-    d4 p1[CH_MB], p2[CH_MB], p3[CH_MB];
+    // tiles P = Q + wave + 8 m of this column, in groups of CH_MB per wave (registers); the first group holds the
+    // diagonal tile, which is factorised before any panel tile is finished
+    const int ngroups = (nt - Q + 8 * CH_MB - 1) / (8 * CH_MB);
+    for (int grp = 0; grp < ngroups; ++grp) {
+      const int Pb = Q + wave + 8 * CH_MB * grp;   // this wave's first tile of the group
+      d4 p1[CH_MB], p2[CH_MB], p3[CH_MB];
 #pragma unroll
-    for (int m = 0; m < CH_MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
-    for (int j = 0; j < Q; ++j) {
-      const double* Bt = T + tile_off(Q, j);
-      double bR[4], bI[4];
+      for (int m = 0; m < CH_MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
+      for (int j = 0; j < Q; ++j) {
+        const double* Bt = T + tile_off(Q, j);
+        double bR[4], bI[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { const int o = (4 * ks + lq) * 16 + lcol; bR[ks] = Bt[o]; bI[ks] = Bt[256 + o]; }
+        for (int ks = 0; ks < 4; ++ks) { const int o = (4 * ks + lq) * 16 + lcol; bR[ks] = Bt[o]; bI[ks] = Bt[256 + o]; }
 #pragma unroll
-      for (int m = 0; m < CH_MB; ++m) {
-        const int P = Q + wave + 8 * m;
-        if (P >= nt) continue;
-        const double* At = T + tile_off(P, j);
+        for (int m = 0; m < CH_MB; ++m) {
+          const int P = Pb + 8 * m;
+          if (P >= nt) continue;
+          const double* At = T + tile_off(P, j);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int o = (4 * ks + lq) * 16 + lcol;
-          const double aR = At[o], aI = At[256 + o];
-          p1[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR[ks], p1[m], 0, 0, 0);
-          p2[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI[ks], p2[m], 0, 0, 0);
-          p3[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI[ks] - bR[ks], p3[m], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) {
+            const int o = (4 * ks + lq) * 16 + lcol;
+            const double aR = At[o], aI = At[256 + o];
+            p1[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR[ks], p1[m], 0, 0, 0);
+            p2[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI[ks], p2[m], 0, 0, 0);
+            p3[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI[ks] - bR[ks], p3[m], 0, 0, 0);
+          }
         }
       }
-    }
-    // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3)
+      // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3)
 #pragma unroll
-    for (int m = 0; m < CH_MB; ++m) {
-      const int P = Q + wave + 8 * m;
-      if (P >= nt) continue;
-      const double* Ct = T + tile_off(P, Q);
+      for (int m = 0; m < CH_MB; ++m) {
+        const int P = Pb + 8 * m;
+        if (P >= nt) continue;
+        const double* Ct = T + tile_off(P, Q);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = (lq + 4 * r) * 16 + lcol;
-        const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
-        const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
-        p1[m][r] = cr; p3[m][r] = ci;
+        for (int r = 0; r < 4; ++r) {
+          const int o = (lq + 4 * r) * 16 + lcol;
+          const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
+          const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
+          p1[m][r] = cr; p3[m][r] = ci;
+        }
       }
-    }
-    if (wave == 0) {   // the diagonal tile is this wave's m = 0
+      if (grp == 0) {
+        if (wave == 0) {   // the diagonal tile is this wave's first tile of the first group
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Dc[2 * ((lq + 4 * r) * 16 + lcol)] = p1[0][r];
-        Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = p3[0][r];
+          for (int r = 0; r < 4; ++r) {
+            Dc[2 * ((lq + 4 * r) * 16 + lcol)] = p1[0][r];
+            Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = p3[0][r];
+          }
+        }
+        diag_init(Zc, tid);
+        __syncthreads();
+        diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid);   // ends with a barrier
+        for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
       }
-    }
-    diag_init(Zc, tid);
-    __syncthreads();
-    diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid);   // ends with a barrier
-    for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
-    // panel tiles: X = C W^H (three real products), stored k-major
+      // panel tiles: X = C W^H (three real products), stored k-major
 #pragma unroll
-    for (int m = 0; m < CH_MB; ++m) {
-      const int P = Q + wave + 8 * m;
-      if (P >= nt || P == Q) continue;
-      double* tr = trb;
-      double* ti = trb + TL_TILE;
+      for (int m = 0; m < CH_MB; ++m) {
+        const int P = Pb + 8 * m;
+        if (P >= nt || P == Q) continue;
+        double* tr = trb;
+        double* ti = trb + TL_TILE;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {   // C[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
-        tr[lcol * TL_LD + lq + 4 * r] = p1[m][r];
-        ti[lcol * TL_LD + lq + 4 * r] = p3[m][r];
-      }
-      __builtin_amdgcn_wave_barrier();
-      d4 x1 = (d4){0, 0, 0, 0}, x2 = (d4){0, 0, 0, 0}, x3 = (d4){0, 0, 0, 0};
+        for (int r = 0; r < 4; ++r) {   // C[row = lq+4r][col = lcol] -> tmp[k = col][i = row]
+          tr[lcol * TL_LD + lq + 4 * r] = p1[m][r];
+          ti[lcol * TL_LD + lq + 4 * r] = p3[m][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        d4 x1 = (d4){0, 0, 0, 0}, x2 = (d4){0, 0, 0, 0}, x3 = (d4){0, 0, 0, 0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int o = (4 * ks + lq) * TL_LD + lcol;
-        const double aR = tr[o], aI = ti[o], bR = WtR[o], bI = WtI[o];
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, x1, 0, 0, 0);
-        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, x2, 0, 0, 0);
-        x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bR + bI, x3, 0, 0, 0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      double* Lt = T + tile_off(P, Q);
+        for (int ks = 0; ks < 4; ++ks) {
+          const int o = (4 * ks + lq) * TL_LD + lcol;
+          const double aR = tr[o], aI = ti[o], bR = WtR[o], bI = WtI[o];
+          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, x1, 0, 0, 0);
+          x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, x2, 0, 0, 0);
+          x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bR + bI, x3, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        double* Lt = T + tile_off(P, Q);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {   // L[i = lq+4r][k = lcol] -> [k][i]
-        Lt[lcol * 16 + lq + 4 * r] = x1[r] - x2[r];
-        Lt[256 + lcol * 16 + lq + 4 * r] = x3[r] - (x1[r] + x2[r]);
+        for (int r = 0; r < 4; ++r) {   // L[i = lq+4r][k = lcol] -> [k][i]
+          Lt[lcol * 16 + lq + 4 * r] = x1[r] - x2[r];
+          Lt[256 + lcol * 16 + lq + 4 * r] = x3[r] - (x1[r] + x2[r]);
+        }
       }
     }
     __syncthreads();   // factor column visible to every wave; Dc / Wt reusable

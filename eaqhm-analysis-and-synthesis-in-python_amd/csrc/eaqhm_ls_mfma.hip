@@ -266,7 +266,7 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 150 * 1024) TS >>= 1;
   const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
-  if ((size_t)2 * TS * ldx_max < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > 8 * CH_MB)
+  if ((size_t)2 * TS * ldx_max < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > CH_NTMAX)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the tile factorisation's work space");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
