@@ -156,6 +156,7 @@ def main():
     torch.cuda.synchronize()
     ls_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "ls"]
     post_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "post"]
+    gather_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "gather"]
     N = 2 * plan.frame_wl[eng.f_lo:eng.f_hi].astype(np.int64) + 1
     flops_per_launch = [float(ls_flops(N, 2 * plan.frame_K[eng.f_lo:eng.f_hi].astype(np.int64) + 1).sum())]
     for nc in eng.ncol_hist[:max(n_adpt - 1, 0)]:
@@ -177,7 +178,8 @@ def main():
                 "flops_per_launch_mean": flops_step / max(launches_per_step, 1),
                 "launch_ms_mean": float(np.mean(ls_ms)) if ls_ms else None,
                 "launches_timed": len(ls_ms),
-                "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None}
+                "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None,
+                "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None}
 
     out = {"metric": "analysis_frames_per_sec", "value": frames_total / dt, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

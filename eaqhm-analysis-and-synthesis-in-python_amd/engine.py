@@ -204,8 +204,11 @@ class DeviceAnalysis:
     def post_launch(self, a):
         """Enqueue interpolation + synthesis + error sums of adaptation `a` (no host read)."""
         p, c, sh = self.plan, self.ctx, self.shard
+        g0 = self._mark()
         sh.all_gather_rows(self.records[0], p.No_ti)
         e0 = self._mark()
+        if self.profile and sh.collective:
+            self.timeline.append((a, "gather", g0, e0))
         c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom, self.sp_lo, self.sp_hi)
         if self.s_hi > self.s_lo:
             c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
