@@ -238,7 +238,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
       live[sl] = x < ntiles;
       int P = 0, Q = 0;
       sys_tile_of(live[sl] ? x : 0, P, Q);
-      tP[sl] = P; tQ[sl] = Q;
+      tP[sl] = __builtin_amdgcn_readfirstlane(P);   // wave-uniform: scalar registers, not spill slots
+      tQ[sl] = __builtin_amdgcn_readfirstlane(Q);
     }
 
     // ================= Gramian =================
