@@ -150,8 +150,16 @@ __device__ inline double scan16(double x) {
 
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
 // the five budgets into one kernel body spills several hundred VGPRs).
+// wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
+// registers): moved to scalar registers, where the arithmetic on them costs no VGPRs and no VALU cycles
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 template <int NS>
-__device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, int ldx_max, double* lds, int f) {
+__device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, int ldx_max_, double* lds, int f_) {
+  const int TS = uni(TS_), ldx_max = uni(ldx_max_), f = uni(f_);
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,10 +190,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
   double* Rs = Qs + (size_t)Npad * A.nmax;                         // Af[j][t]
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
-  const int mode = A.mode;
+  const int mode = uni(A.mode);
   // phases are q * (2 pi / fs) here, (2 pi q) / fs in the reference (functions.py:513, :453): one rounding each way,
   // <= 2 ulp of the phase apart, and no IEEE division per basis sample
-  const double w1 = 2.0 * M_PI / A.fs;
+  const double w1 = uni(2.0 * M_PI / A.fs);
   const int PE = TS / 2;
   const int lcol = lane & 15, lq = lane >> 4;
   unsigned long long* dbg = A.debug;
@@ -200,28 +208,28 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS, in
   } while (0)
 
   {
-    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
+    const int n = uni((mode == 0) ? A.frame_K[f] : A.ncol[f]);
     const int Kc = 2 * n + 1, Ms = 2 * Kc + 1;   // stacked columns incl. the signal
     const int nt = (Ms + 15) >> 4;
-    const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
+    const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
     const int N = 2 * wl + 1, mid = wl;
     const int ldx = (nt << 4) + ((nt & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
     const int ntiles = nt * (nt + 1) / 2;
     const int is = 2 * Kc - 16 * (nt - 1);  // position of the signal column inside the last tile row (2,6,10,14)
-    const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
-    const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
+    const double f0 = uni((mode == 0) ? A.frame_f0[f] : A.f0_stale);
+    const int* mycols = (mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
     for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
     for (int t = tid; t < N; t += nt_thr) {
-      win[t] = window_value(A.mode == 0, t, N);
+      win[t] = window_value(mode == 0, t, N);
       sig[t] = A.s[(size_t)(c - wl) + t];
     }
     __syncthreads();
     int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
-    if (A.mode == 1) prepare_slots(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, f);
+    if (mode == 1) prepare_slots(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, f);
     STAMP(0);
 
     // system tiles of this wave
