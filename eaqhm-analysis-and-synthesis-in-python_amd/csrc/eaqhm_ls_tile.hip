@@ -156,6 +156,13 @@ __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline double uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+template <typename T>
+__device__ inline T* uni(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
 
 template <int NS>
 __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, int ldx_max_, double* lds, int f_) {
@@ -164,7 +171,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- LDS carve-up: region U is the basis chunk (+ slot info) in the Gramian phase, tile storage afterwards
-  double* U = lds;
+  double* U = uni(lds);
   double* Xre = U;
   double* Xim = Xre + (size_t)TS * ldx_max;
   const size_t usize_g = (size_t)2 * TS * ldx_max;
@@ -182,21 +189,22 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   double* xv = zv + 2 * 16 * TL_NTMAX;               // 2*16
   const size_t usize_c = (size_t)(xv + 32 - U);
   double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
-  double* sh = xs + 4 * A.Kcmax;                     // 16
+  double* sh = xs + 4 * uni(A.Kcmax);                // 16
   double* win = sh + 16;                             // [64*CI_NCH] analysis window of the frame
   double* sig = win + 64 * CI_NCH;                   // [64*CI_NCH] signal window of the frame
 
-  const int Npad = ((A.Nmax + 63) >> 6) << 6;
-  double* Qs = A.scratch + (size_t)blockIdx.x * A.scratch_stride;  // Qloc[j][t]
-  double* Rs = Qs + (size_t)Npad * A.nmax;                         // Af[j][t]
-  const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
+  const int Npad = ((uni(A.Nmax) + 63) >> 6) << 6;
+  double* Qs = uni(A.scratch) + (size_t)blockIdx.x * (size_t)uni((int)A.scratch_stride);  // bridged fm[j][t]
+  double* Rs = Qs + (size_t)Npad * uni(A.nmax);                                           // bridged am[j][t]
   const int mode = uni(A.mode);
+  const bool seeds = uni((int)((mode == 1) && A.any_seed && (*A.any_seed != 0))) != 0;
   // phases are q * (2 pi / fs) here, (2 pi q) / fs in the reference (functions.py:513, :453): one rounding each way,
   // <= 2 ulp of the phase apart, and no IEEE division per basis sample
   const double w1 = uni(2.0 * M_PI / A.fs);
   const int PE = TS / 2;
+  const double* sA = uni(A.s);
   const int lcol = lane & 15, lq = lane >> 4;
-  unsigned long long* dbg = A.debug;
+  unsigned long long* dbg = uni(A.debug);
   unsigned long long t_prev = 0;
 #define STAMP(ph)                                                   \
   do {                                                              \
@@ -217,7 +225,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     const int ntiles = nt * (nt + 1) / 2;
     const int is = 2 * Kc - 16 * (nt - 1);  // position of the signal column inside the last tile row (2,6,10,14)
     const double f0 = uni((mode == 0) ? A.frame_f0[f] : A.f0_stale);
-    const int* mycols = (mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
+    const int* mycols = (mode == 1) ? (uni(A.cols) + (size_t)f * uni(A.Kmax)) : nullptr;
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
@@ -225,7 +233,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
     for (int t = tid; t < N; t += nt_thr) {
       win[t] = window_value(mode == 0, t, N);
-      sig[t] = A.s[(size_t)(c - wl) + t];
+      sig[t] = sA[(size_t)(c - wl) + t];
     }
     __syncthreads();
     int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
