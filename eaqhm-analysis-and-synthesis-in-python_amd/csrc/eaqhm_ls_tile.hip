@@ -241,7 +241,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     STAMP(0);
 
     // system tiles of this wave
-    constexpr bool M3 = (NS <= 5);   // register budget: a third accumulator per tile only for the smaller frames
+    constexpr bool M3 = (NS <= 7);   // register budget: a third accumulator per tile only for the smaller frames
     d4 accR[NS], accI[NS], acc3[M3 ? NS : 1];
     int tP[NS], tQ[NS];
     bool live[NS];
