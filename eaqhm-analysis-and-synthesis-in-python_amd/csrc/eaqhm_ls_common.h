@@ -27,6 +27,20 @@ struct LsArgs {
   unsigned long long* debug;  // phase stamps (16 x u64)
 };
 
+// wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
+// registers): moved to scalar registers, where the arithmetic on them costs no VGPRs and no VALU cycles
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <typename T>
+__device__ inline T* uni(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 // seed-aware track access (functions.py:209-210; see eaqhm_frame_prep): a seeded row shows 140 Hz / 10e-4
 // in slot 0 to the frames at or after it, exactly like the sequential write of the reference
 __device__ inline double track_fm(const LsArgs& A, int k, long long t, int c, bool seeds) {

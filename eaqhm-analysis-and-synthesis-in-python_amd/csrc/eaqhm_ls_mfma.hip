@@ -81,20 +81,21 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
   for (;;) {
     if (tid == 0) shi[0] = atomicAdd((min_nb > 0) ? (A.cls + 8 + 5) : A.work_counter, 1);
     __syncthreads();
-    const int item = shi[0];
+    const int item = uni(shi[0]);
     __syncthreads();
     if (item >= n_items) break;
-    const int f = (min_nb > 0) ? A.cls[16 + (size_t)5 * A.n_frames + item] : item;
-    const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
+    // (wave-uniform, but out of LDS / memory: scalar registers for everything derived from them)
+    const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)5 * A.n_frames + item] : item);
+    const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
     const int N = 2 * wl + 1, mid = wl;
-    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
+    const int n = uni((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
     const int Kc = 2 * n + 1, C1 = Kc + 1;
     const int nbk = (Kc + 15) >> 4, ntl = 2 * nbk + 1;   // stacked padded tile rows (eaqhm_ls_chol.h)
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
     const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
     const int npass = (units + MF_WAVES * MF_NSLOT - 1) / (MF_WAVES * MF_NSLOT);
-    const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
+    const double f0 = uni((A.mode == 0) ? A.frame_f0[f] : A.f0_stale);
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 

@@ -150,20 +150,6 @@ __device__ inline double scan16(double x) {
 
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
 // the five budgets into one kernel body spills several hundred VGPRs).
-// wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
-// registers): moved to scalar registers, where the arithmetic on them costs no VGPRs and no VALU cycles
-__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline double uni(double v) {
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-template <typename T>
-__device__ inline T* uni(T* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-  return (T*)(((unsigned long long)hi << 32) | lo);
-}
-
 template <int NS>
 __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, int ldx_max_, double* lds, int f_) {
   const int TS = uni(TS_), ldx_max = uni(ldx_max_), f = uni(f_);
