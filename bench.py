@@ -188,7 +188,7 @@ def main():
                    "reference's SWIPE'" % reps,
            "config": {"workload": "sa19x%d_female_maxAdpt%d" % (reps, args.max_adpt), "samples": int(plan.L),
                       "fs": int(fs), "ls_frames_per_adaptation": int(plan.n_frames), "adaptations_executed": n_adpt,
-                      "Kmax": int(plan.Kmax), "parallelism": "frames sharded x%d, all-gather of records" % world},
+                      "Kmax": int(plan.Kmax), "parallelism": "frames sharded x%d, all-gather of boundary records per adaptation" % world},
            "final_srer_db": max(srer), "srer_db": srer, "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

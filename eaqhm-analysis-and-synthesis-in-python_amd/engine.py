@@ -3,7 +3,8 @@ instants of each adaptation sharded over the ranks (one process per GPU).
 
 Per adaptation a rank runs
     [frame_prep] -> ls_batch            its own contiguous range of analysis instants
-    all-gather of the frame-centre records (RCCL over xGMI; skipped when world_size == 1)
+    all-gather (RCCL over xGMI) of the frame-centre records its neighbours' interpolation reads: the boundary
+    rows of every rank's range (Sharding.share_rows); the complete records are gathered once, with the results
     spline_solve                        every rank, the instants its own time range looks at
     eval_synth                          its own time range plus a halo of max(wl) samples, so the dense
                                         tracks its frames will window in the next adaptation are local
@@ -74,13 +75,45 @@ class Sharding:
         c = self.chunk(n_instants)
         return min(r * c, n_instants), min((r + 1) * c, n_instants)
 
+    def _all_gather_into(self, out, part):
+        """out = concatenation over ranks of `part` (RCCL all-gather; `part` may be a slice of `out`)."""
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(out, part, group=self.group)
+
     def all_gather_rows(self, buf, n_instants):
         """In-place all-gather: every rank contributes rows [rank*chunk, (rank+1)*chunk) of `buf`."""
         if not self.collective:
             return
-        import torch.distributed as dist
         c = self.chunk(n_instants)
-        dist.all_gather_into_tensor(buf, buf[self.rank * c:(self.rank + 1) * c], group=self.group)
+        self._all_gather_into(buf, buf[self.rank * c:(self.rank + 1) * c])
+
+    def share_rows(self, buf, n_instants, margin):
+        """What the interpolation of one rank's time range reads from the other ranks' rows of `buf`: the `margin`
+        rows on either side of its own range and the first rows of the file (pad knots of short runs).  Every rank
+        contributes the first and the last `margin` rows of its range to one small all-gather and copies its two
+        neighbours' parts into place; the full rows are gathered once, when the results are collected
+        (all_gather_rows).  Falls back to the full all-gather when the ranges are shorter than the margin.
+        Returns True if only boundary rows were exchanged."""
+        if not self.collective:
+            return False
+        c = self.chunk(n_instants)
+        if margin < 4 or c < margin:
+            self.all_gather_rows(buf, n_instants)
+            return False
+        import torch
+        r, m = self.rank, margin
+        lo = r * c
+        part = torch.cat((buf[lo:lo + m], buf[lo + c - m:lo + c]))
+        got = buf.new_empty((self.world * 2 * m, buf.shape[1]))
+        self._all_gather_into(got, part)
+        if r > 0:
+            buf[lo - m:lo].copy_(got[(r - 1) * 2 * m + m:(r - 1) * 2 * m + 2 * m])     # left neighbour's last rows
+            k = min(m, lo - m)                                                          # rank 0's first rows
+            if k > 0:
+                buf[0:k].copy_(got[0:k])
+        if r < self.world - 1:
+            buf[lo + c:lo + c + m].copy_(got[(r + 1) * 2 * m:(r + 1) * 2 * m + m])     # right neighbour's first rows
+        return True
 
     def all_reduce_sum(self, t):
         if not self.collective:
@@ -124,6 +157,10 @@ class DeviceAnalysis:
         self.s_lo, self.s_hi = bound(sh.rank), bound(sh.rank + 1)
         self.t_lo = max(0, self.s_lo - p.wl_max)
         self.t_hi = min(L, self.s_hi + p.wl_max)
+        # rows of the other ranks' records the interpolation of [t_lo, t_hi) reads: the halo, the spline range beyond it
+        # (+-2, +4), run detection (+-41)
+        self.margin = -(-p.wl_max // p.step) + 48
+        self.partial_rows = False
         # instants whose run codes / spline moments the evaluation of [t_lo, t_hi) looks at
         self.sp_lo = max(0, (max(self.t_lo, 1) - 1) // p.step - 2)
         self.sp_hi = max(self.sp_lo + 1, min(T, (max(self.t_hi, 1) - 1) // p.step + 4))
@@ -205,7 +242,7 @@ class DeviceAnalysis:
         """Enqueue interpolation + synthesis + error sums of adaptation `a` (no host read)."""
         p, c, sh = self.plan, self.ctx, self.shard
         g0 = self._mark()
-        sh.all_gather_rows(self.records[0], p.No_ti)
+        self.partial_rows = sh.share_rows(self.records[0], p.No_ti, self.margin) or self.partial_rows
         e0 = self._mark()
         if self.profile and sh.collective:
             self.timeline.append((a, "gather", g0, e0))
@@ -289,6 +326,8 @@ class DeviceAnalysis:
         s_recon and its own instants of the phases; they are merged here, once, outside the loop.)"""
         p, K, sh = self.plan, self.plan.Kmax, self.shard
         s_hat, ph = self.s_hat[1], self.ph_knot[1]
+        if sh.collective and self.partial_rows:      # only boundary rows travelled during the loop
+            sh.all_gather_rows(self.records[1], p.No_ti)
         if sh.collective:
             s_hat = s_hat.clone()
             s_hat[:self.s_lo] = 0

@@ -23,11 +23,10 @@ def _worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     class HostStaged(Sharding):
-        def all_gather_rows(self, buf, n_instants):
-            c = self.chunk(n_instants)
-            host = buf.cpu()
-            dist.all_gather_into_tensor(host, host[self.rank * c:(self.rank + 1) * c].clone(), group=self.group)
-            buf.copy_(host)
+        def _all_gather_into(self, out, part):
+            host = out.cpu()
+            dist.all_gather_into_tensor(host, part.cpu().clone(), group=self.group)
+            out.copy_(host)
 
         def all_reduce_sum(self, t):
             host = t.cpu()

@@ -140,13 +140,15 @@ def _sharded_worker(rank, world, port, out_path):
 
 
 @pytest.mark.slow
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_gloo_matches_single_process(tmp_path, world):
+    """world 4 has interior ranks (two neighbours each) for the boundary-row exchange."""
     import torch.multiprocessing as mp
     import eaqhm_oracle as O
     from eaqhm_amd import prologue
     from eaqhm_amd.synth import synth_speech_int16
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_sharded_worker, args=(2, 29000 + os.getpid() % 2000, out), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(world, 29000 + os.getpid() % 2000 + world, out), nprocs=world, join=True)
     got = np.load(out)
     fs = 16000
     s = synth_speech_int16(0.62, fs) / 32768.0
