@@ -59,10 +59,18 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
   const double eps = 10e-5;  // functions.py:517
   const int nch = (N + 63) >> 6;
   const long long t0 = (long long)c - wl;
+  // the argument block is read through a per-lane pointer: fetch what this function uses once, into scalars
+  const unsigned short* zloc = uni(A.zloc);
+  const int* ztot = uni(A.ztot);
+  const double* fm_all = uni(A.fm_cur);
+  const double* am_all = uni(A.am_cur);
+  const long long L = ((long long)uni((int)(A.L >> 32)) << 32) | (unsigned)uni((int)(A.L & 0xffffffffll));
+  const int zchunks = uni(A.zchunks);
+  const double w1 = uni(2.0 * M_PI / A.fs);
   auto centre = [&](int j, double fv, double av) {
     ci[j * CI_STRIDE + 17] = 1.0 / (av + eps);
     double sn, cs;
-    sincos_cw((2.0 * M_PI * fv) / A.fs, &sn, &cs);
+    sincos_cw(fv * w1, &sn, &cs);
     ci[j * CI_STRIDE + 18] = cs;
     ci[j * CI_STRIDE + 19] = sn;
   };
@@ -73,18 +81,18 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
     const int k = mycols[j];
     const long long b = (long long)c + wl, a1 = (long long)c - wl - 1;
     const int cb = (int)(b >> 10), ca = (a1 >= 0) ? (int)(a1 >> 10) : 0;
-    int zc = A.zloc[(size_t)k * A.L + b] + ((cb != ca) ? A.ztot[(size_t)k * A.zchunks + ca] : 0);
-    if (a1 >= 0) zc -= A.zloc[(size_t)k * A.L + a1];
+    int zc = zloc[(size_t)k * L + b] + ((cb != ca) ? ztot[(size_t)k * zchunks + ca] : 0);
+    if (a1 >= 0) zc -= zloc[(size_t)k * L + a1];
     const int g = (zc != 0 || (seeds && k == 0)) ? 1 : 0;
     gappy[j] = g;
     anyg |= g;
     ci[j * CI_STRIDE + 0] = 0.0;
     ci[j * CI_STRIDE + 1] = 0.0;
     // where the build reads this slot's window from: the bridged copy or the track itself
-    const size_t trk = (size_t)k * A.L + t0;
-    ((const double**)(ci + j * CI_STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (A.fm_cur + trk);
-    ((const double**)(ci + j * CI_STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (A.am_cur + trk);
-    if (!g) centre(j, track_fm(A, k, c, c, seeds), track_am(A, k, c, c, seeds));
+    const size_t trk = (size_t)k * L + t0;
+    ((const double**)(ci + j * CI_STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (fm_all + trk);
+    ((const double**)(ci + j * CI_STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (am_all + trk);
+    if (!g) centre(j, fm_all[(size_t)k * L + c], am_all[(size_t)k * L + c]);   // (a seeded slot 0 is never gap-free)
   }
   if (!__syncthreads_or(anyg)) return;
   // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
