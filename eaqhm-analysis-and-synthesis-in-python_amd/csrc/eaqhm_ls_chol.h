@@ -8,6 +8,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define TL_LD 17        // tile row stride in LDS (doubles): conflict-free transposing stores
 #define TL_TILE (16 * TL_LD)
+#define DG_LD 17        // row stride (complex entries) of the diagonal tile and its inverse in LDS: the sixteen rows of
+                        // a column start in different banks (a stride of 16 complex = 256 B puts them all in one)
+#define DG_TILE (2 * 16 * DG_LD)   // doubles per tile
 
 // ---- diagonal tile: Cholesky factor L and W = L^-1 of a 16x16 Hermitian positive definite tile, by the whole
 // workgroup.  The sixteen column steps are a serial chain on the critical path of the frame, so each step is
@@ -18,7 +21,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // identity into Z, to be called before the barrier that publishes the diagonal tile in D
 __device__ inline void diag_init(double* Z, int tid) {
   const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;
-  if (g == 1) { Z[2 * e] = (i == k) ? 1.0 : 0.0; Z[2 * e + 1] = 0.0; }
+  if (g == 1) { Z[2 * (i * DG_LD + k)] = (i == k) ? 1.0 : 0.0; Z[2 * (i * DG_LD + k) + 1] = 0.0; }
 }
 
 __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
@@ -28,44 +31,45 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
   // block stay raw until the final scaling, which applies the block's own 2x2 Cholesky factor.
   // (Z must hold the identity and D the tile when the workgroup arrives here: diag_init + the caller's barrier)
   const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
+  const int eo = i * DG_LD + k;                                    // ... at its padded position
 #pragma clang loop unroll(disable)
   for (int j = 0; j < 14; j += 2) {
     const bool work = (g == 0) ? (k >= j + 2 && i >= k) : (i >= j + 2 && k <= j + 1);
     if (work) {
-      double p = D[2 * (j * 16 + j)], r = D[2 * ((j + 1) * 16 + j + 1)];
-      const double qr = D[2 * ((j + 1) * 16 + j)], qi = D[2 * ((j + 1) * 16 + j) + 1];
+      double p = D[2 * (j * DG_LD + j)], r = D[2 * ((j + 1) * DG_LD + j + 1)];
+      const double qr = D[2 * ((j + 1) * DG_LD + j)], qi = D[2 * ((j + 1) * DG_LD + j) + 1];
       p = (p > 0.0) ? p : 1.0;
       double det = p * r - (qr * qr + qi * qi);
       det = (det > 0.0) ? det : 1.0;   // only the RHS position of the last tile can get here (residual ~ 0)
       double dinv = __builtin_amdgcn_rcp(det);
       dinv = dinv * fma(-det, dinv, 2.0);
       dinv = dinv * fma(-det, dinv, 2.0);
-      const double a1r = D[2 * (i * 16 + j)], a1i = D[2 * (i * 16 + j) + 1];
-      const double a2r = D[2 * (i * 16 + j + 1)], a2i = D[2 * (i * 16 + j + 1) + 1];
+      const double a1r = D[2 * (i * DG_LD + j)], a1i = D[2 * (i * DG_LD + j) + 1];
+      const double a2r = D[2 * (i * DG_LD + j + 1)], a2i = D[2 * (i * DG_LD + j + 1) + 1];
       // y = P^-1 [x1; x2] * det = [ r x1 - conj(q) x2 ;  -q x1 + p x2 ],  then  out -= (a1 y1 + a2 y2) / det
       double x1r, x1i, x2r, x2i;
       if (g == 0) {   // x = b^H components: conj(D[k][j]), conj(D[k][j+1])
-        x1r = D[2 * (k * 16 + j)];     x1i = -D[2 * (k * 16 + j) + 1];
-        x2r = D[2 * (k * 16 + j + 1)]; x2i = -D[2 * (k * 16 + j + 1) + 1];
+        x1r = D[2 * (k * DG_LD + j)];     x1i = -D[2 * (k * DG_LD + j) + 1];
+        x2r = D[2 * (k * DG_LD + j + 1)]; x2i = -D[2 * (k * DG_LD + j + 1) + 1];
       } else {        // x = Z[j][k], Z[j+1][k]
-        x1r = Z[2 * (j * 16 + k)];       x1i = Z[2 * (j * 16 + k) + 1];
-        x2r = Z[2 * ((j + 1) * 16 + k)]; x2i = Z[2 * ((j + 1) * 16 + k) + 1];
+        x1r = Z[2 * (j * DG_LD + k)];       x1i = Z[2 * (j * DG_LD + k) + 1];
+        x2r = Z[2 * ((j + 1) * DG_LD + k)]; x2i = Z[2 * ((j + 1) * DG_LD + k) + 1];
       }
       const double y1r = r * x1r - (qr * x2r + qi * x2i), y1i = r * x1i - (qr * x2i - qi * x2r);   // conj(q) x2
       const double y2r = p * x2r - (qr * x1r - qi * x1i), y2i = p * x2i - (qr * x1i + qi * x1r);   // q x1
       const double ur = (a1r * y1r - a1i * y1i) + (a2r * y2r - a2i * y2i);
       const double ui = (a1r * y1i + a1i * y1r) + (a2r * y2i + a2i * y2r);
       double* T = (g == 0) ? D : Z;
-      T[2 * e] -= ur * dinv;
-      T[2 * e + 1] -= ui * dinv;
+      T[2 * eo] -= ur * dinv;
+      T[2 * eo + 1] -= ui * dinv;
     }
     __syncthreads();
   }
   // final scaling with each pivot block's own Cholesky factor [[l11, 0], [l21, l22]]
   {
     const int pj = ((g == 0) ? k : i) & ~1;    // first column (D) / row (Z) of the entry's pivot block
-    double p = D[2 * (pj * 16 + pj)], r = D[2 * ((pj + 1) * 16 + pj + 1)];
-    const double qr = D[2 * ((pj + 1) * 16 + pj)], qi = D[2 * ((pj + 1) * 16 + pj) + 1];
+    double p = D[2 * (pj * DG_LD + pj)], r = D[2 * ((pj + 1) * DG_LD + pj + 1)];
+    const double qr = D[2 * ((pj + 1) * DG_LD + pj)], qi = D[2 * ((pj + 1) * DG_LD + pj) + 1];
     p = (p > 0.0) ? p : 1.0;
     double i11 = __builtin_amdgcn_rsq(p);
     i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
@@ -83,13 +87,13 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
       else if (!second) {                       // column pj
         if (i == pj) { lr = p * i11; li = 0.0; }
         else if (i == pj + 1) { lr = l21r; li = l21i; }
-        else { lr = D[2 * e] * i11; li = D[2 * e + 1] * i11; }
+        else { lr = D[2 * eo] * i11; li = D[2 * eo + 1] * i11; }
       } else {                                  // column pj+1
         if (i == pj + 1) { lr = s22 * i22; li = 0.0; }
         else {   // (a2 - (a1 / l11) conj(l21)) / l22
-          const double a1r = D[2 * (i * 16 + pj)] * i11, a1i = D[2 * (i * 16 + pj) + 1] * i11;
-          lr = (D[2 * e] - (a1r * l21r + a1i * l21i)) * i22;
-          li = (D[2 * e + 1] - (a1i * l21r - a1r * l21i)) * i22;
+          const double a1r = D[2 * (i * DG_LD + pj)] * i11, a1i = D[2 * (i * DG_LD + pj) + 1] * i11;
+          lr = (D[2 * eo] - (a1r * l21r + a1i * l21i)) * i22;
+          li = (D[2 * eo + 1] - (a1i * l21r - a1r * l21i)) * i22;
         }
       }
       LdR[i * TL_LD + k] = lr;
@@ -97,11 +101,11 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
     } else {   // W rows of the block: W[pj] = Z[pj] / l11,  W[pj+1] = (Z[pj+1] - l21 W[pj]) / l22;  stored as W^H
       double wr = 0.0, wi = 0.0;
       if (k <= i) {
-        const double z1r = Z[2 * (pj * 16 + k)] * i11, z1i = Z[2 * (pj * 16 + k) + 1] * i11;
+        const double z1r = Z[2 * (pj * DG_LD + k)] * i11, z1i = Z[2 * (pj * DG_LD + k) + 1] * i11;
         if ((i & 1) == 0) { wr = z1r; wi = z1i; }
         else {
-          wr = (Z[2 * e] - (l21r * z1r - l21i * z1i)) * i22;
-          wi = (Z[2 * e + 1] - (l21r * z1i + l21i * z1r)) * i22;
+          wr = (Z[2 * eo] - (l21r * z1r - l21i * z1i)) * i22;
+          wi = (Z[2 * eo + 1] - (l21r * z1i + l21i * z1r)) * i22;
         }
       }
       WtR[k * TL_LD + i] = wr;
@@ -130,7 +134,7 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
 #define CH_MB 6          // tiles per wave, column and register group
 #define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
-#define CH_LDS_DOUBLES (512 + 512 + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32)
+#define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32)
 
 // T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
 __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, int nt, int Kc, int nbk,
@@ -138,8 +142,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
   const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* Dc = lds;
-  double* Zc = Dc + 512;
-  double* WtR = Zc + 512;
+  double* Zc = Dc + DG_TILE;
+  double* WtR = Zc + DG_TILE;
   double* WtI = WtR + TL_TILE;
   double* LdR = WtI + TL_TILE;
   double* LdI = LdR + TL_TILE;
@@ -194,8 +198,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         if (wave == 0) {   // the diagonal tile is this wave's first tile of the first group
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            Dc[2 * ((lq + 4 * r) * 16 + lcol)] = p1[0][r];
-            Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = p3[0][r];
+            Dc[2 * ((lq + 4 * r) * DG_LD + lcol)] = p1[0][r];
+            Dc[2 * ((lq + 4 * r) * DG_LD + lcol) + 1] = p3[0][r];
           }
         }
         diag_init(Zc, tid);

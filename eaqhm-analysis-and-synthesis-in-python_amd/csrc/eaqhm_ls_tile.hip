@@ -177,9 +177,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   double* WtI = WtR + TL_NTMAX * TL_TILE;
   double* LdR = WtI + TL_NTMAX * TL_TILE;            // [TILE]      last diagonal factor, [row][col]
   double* LdI = LdR + TL_TILE;
-  double* Dc = LdI + TL_TILE;                        // [512]       diagonal tile being factorised (complex, row-major)
-  double* Zc = Dc + 512;                             // [512]       its inverse in the making
-  double* zv = Zc + 512;                        // 2*16*NT
+  double* Dc = LdI + TL_TILE;                        // [DG_TILE]   diagonal tile being factorised (complex, rows DG_LD apart)
+  double* Zc = Dc + DG_TILE;                         // [DG_TILE]   its inverse in the making
+  double* zv = Zc + DG_TILE;                        // 2*16*NT
   double* xv = zv + 2 * 16 * TL_NTMAX;               // 2*16
   const size_t usize_c = (size_t)(xv + 32 - U);
   double* xs = U + usize_c;                          // 4*Kcmax   solution in natural order
@@ -442,8 +442,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             if (sl == sd) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                Dc[2 * ((lq + 4 * r) * 16 + lcol)] = accR[sl][r];
-                Dc[2 * ((lq + 4 * r) * 16 + lcol) + 1] = accI[sl][r];
+                Dc[2 * ((lq + 4 * r) * DG_LD + lcol)] = accR[sl][r];
+                Dc[2 * ((lq + 4 * r) * DG_LD + lcol) + 1] = accI[sl][r];
               }
             }
         }
@@ -656,7 +656,7 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
 }
 
 static size_t tl_usize_c() {
-  return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 1024 + 2 * 16 * TL_NTMAX + 32;
+  return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 2 * DG_TILE + 2 * 16 * TL_NTMAX + 32;
 }
 static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH + 32; }
 static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
