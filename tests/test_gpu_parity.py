@@ -226,6 +226,24 @@ def test_voiced_only_option(amd):
     assert np.abs(s_recon - g["s_recon"]).max() <= 1e-9
 
 
+def test_spline_range_equals_full_solve(sa19_run):
+    """eaqhm_spline_solve_range on a sub-range of the instants gives, inside the range, the run codes and moments of
+    the full solve (what a rank of a sharded run relies on); rows 0..3 of the codes are always produced."""
+    import torch
+    eng = sa19_run["eng"]
+    p, c = eng.plan, eng.ctx
+    rec = eng.records[1]
+    code_f, mom_f = torch.zeros_like(eng.code), torch.zeros_like(eng.mom)
+    c.spline_solve(rec, p.No_ti, p.Kmax, p.step, code_f, mom_f)
+    for lo, hi in ((0, 500), (1800, 2600), (p.No_ti - 300, p.No_ti)):
+        code_r = torch.full_like(eng.code, 99)
+        mom_r = torch.full_like(eng.mom, 1e300)
+        c.spline_solve(rec, p.No_ti, p.Kmax, p.step, code_r, mom_r, lo, hi)
+        torch.cuda.synchronize()
+        assert torch.equal(code_r[lo:hi], code_f[lo:hi]) and torch.equal(code_r[:4], code_f[:4])
+        assert torch.equal(mom_r[lo:hi], mom_f[lo:hi])
+
+
 # ----------------------------------------------------------------------------- against the oracle
 @pytest.mark.parametrize("params", [dict(step=15, pitchPeriods=3, analysisWindow=32, partials=0),
                                     dict(step=10, pitchPeriods=4, analysisWindow=50, partials=20),
