@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — analysis frames/s of the eaQHM hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py [--workload W] --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete run of the adaptation loop (functions.py:163-402) over the workload:
-adaptation 0..maxAdpt or until the reference's stop rule fires.  Inputs (signal, pitch grid, frame
-tables) are resident in HBM before the timed region; result packing into Python structs is outside it
-(SURVEY.md §8d).  Workload at N GPUs = SA19.WAV tiled N times ("sa19x<N>", weak scaling: the frames per
-GPU stay fixed), `female`, maxAdpt=5 — at N=1 this is BASELINE.json configs[1].  Pitch tracks come from
-committed fixtures produced by the reference's SWIPE' (tests/golden), because the reference cannot travel
-to the GPU box.
+Called as plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment) it starts the N ranks
+itself, as fresh child processes, before anything touches a GPU; rank 0 prints the one JSON line.
+
+A "step" is one complete run of the adaptation loop (functions.py:163-402) over the workload: adaptation
+0..maxAdpt or until the reference's stop rule fires.  Inputs (signal, pitch grid, frame tables) are resident in HBM
+before the timed region; result packing into Python structs is outside it.
+
+Workloads (BASELINE.json configs):
+    synth16k_60s  (default) synthetic 60 s speech @16 kHz, `female`, maxAdpt=5 — configs[3], the workload
+                  `north_star` quotes the frames/s metric on; 63,936 LS frames per adaptation
+    synth48k_60s  the same generator at 48 kHz — configs[4]; 191,936 large frames per adaptation
+    sa19          SA19.WAV — configs[1];  sa19x10 — configs[2]
+With N > 1 the SAME signal is sharded over the ranks by analysis instants (strong scaling, as config 4 is written).
+Pitch grids come from committed fixtures produced by the reference's own SWIPE' (tests/golden), because the
+reference cannot travel to the GPU box.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,57 +36,103 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 (vector = matrix) spec: half the 157.3 TF FP32 vector peak
-                          # of MI355X_MICROARCH.md's chip table; measured here: mfma_f64 48, v_fma_f64 63 TF/s
+                          # of MI355X_MICROARCH.md's chip table
+WORKLOADS = ("synth16k_60s", "synth48k_60s", "sa19", "sa19x10")
 
 
 def ls_flops(N, Kc):
-    """Algorithmic FP64 flops of one frame's least squares:
-    Hermitian 3-block Gramian + RHS + complex Cholesky + two triangular solves."""
-    N = np.asarray(N, dtype=np.float64)
-    Kc = np.asarray(Kc, dtype=np.float64)
-    return 12 * N * Kc * (Kc + 1) + 8 * N * Kc + (32.0 / 3.0) * Kc ** 3 + 32 * Kc ** 2
+    """Algorithmic FP64 flops of one frame's least squares."""
+    from eaqhm_amd.engine import ls_cost
+    return ls_cost(N, Kc)
 
 
-def load_workload(reps):
+def load_signal(workload):
+    """(fs, float signal, 5 ms pitch grid or 1 ms track)."""
     from scipy.io import wavfile
+    from eaqhm_amd.synth import synth_speech_int16
+    if workload.startswith("sa19"):
+        reps = int(workload[5:]) if len(workload) > 4 else 1
+        fs, x = wavfile.read(os.path.join(GOLDEN, "SA19.WAV"))
+        x = np.tile(x, reps)
+        if reps == 1:
+            track = np.load(os.path.join(GOLDEN, "sa19_female_default.npz"))["swipe_track"]
+        else:
+            track = np.load(os.path.join(GOLDEN, "prep_fixtures.npz"))["sa19x%d_f0s_5ms" % reps]
+        return fs, x / 32768.0, track
+    fs, track = load_track(workload)
+    return fs, synth_speech_int16(60.0, fs) / 32768.0, track
+
+
+def load_track(workload):
+    """(fs, 5 ms pitch grid the reference's SWIPE' + getLinear produced for the synthetic workload)."""
+    if workload == "synth16k_60s":
+        return 16000, np.load(os.path.join(GOLDEN, "prep_fixtures.npz"))["synth16k_60s_f0s_5ms"]
+    if workload == "synth48k_60s":
+        return 48000, np.load(os.path.join(GOLDEN, "prep_synth48k_60s.npz"))["synth48k_60s_f0s_5ms"]
+    raise SystemExit("unknown workload %s (choose from %s)" % (workload, ", ".join(WORKLOADS)))
+
+
+def load_workload(workload):
     from eaqhm_amd import prologue
-    fs, x = wavfile.read(os.path.join(GOLDEN, "SA19.WAV"))
-    x = np.tile(x, reps)
-    s = x / 32768.0
-    if reps == 1:
-        track = np.load(os.path.join(GOLDEN, "sa19_female_default.npz"))["swipe_track"]
-    else:
-        g = np.load(os.path.join(GOLDEN, "prep_fixtures.npz"))
-        key = "sa19x%d_f0s_5ms" % reps
-        if key not in g.files:
-            raise SystemExit("no pitch fixture for SA19 x%d (available: x2, x4, x8, x10)" % reps)
-        track = g[key]
+    fs, s, track = load_signal(workload)
     grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     prologue.apply_full_waveform(frames, len(s), 32 * 15)
     return fs, s, grid, frames, fstep
 
 
-def cpu_baseline():
-    """The oracle (NumPy port of the reference's path) on a bounded sample of the same workload:
-    SA19.WAV, adaptations 0 and 1 (8,338 LS frames), on this host's cores."""
+def cpu_baseline(workload):
+    """The oracle (NumPy port of the reference's path) on a bounded excerpt of the same workload, on this host's
+    cores: once with one BLAS thread and once with all the cores this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import eaqhm_oracle as O
-    g = np.load(os.path.join(GOLDEN, "sa19_female_default.npz"))
-    from scipy.io import wavfile
-    fs, x = wavfile.read(os.path.join(GOLDEN, "SA19.WAV"))
-    s = x / 32768.0
     from threadpoolctl import threadpool_limits
-    threads = min(8, os.cpu_count() or 1)      # small matrices: more BLAS threads only add contention
-    with threadpool_limits(limits=threads):
-        t0 = time.time()
-        r = O.analyse(s, fs, g["f0s_5ms"], g["vuv_ti"], g["vuv_isSpeech"], g["vuv_isVoiced"], int(g["frame_step"]),
-                      f0min=160, maxAdpt=1)
-        dt = time.time() - t0
-    return {"value": r["n_ls_frames"] / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "SA19.WAV, adaptations 0-1 (%d LS frames, %.1f s), oracle/eaqhm_oracle.py, host has %d cores"
-                      % (r["n_ls_frames"], dt, os.cpu_count()),
-            "srer_db": [float(v) for v in r["SRER"]]}
+    from eaqhm_amd.synth import synth_speech_int16
+    if workload.startswith("sa19"):          # SA19.WAV itself, adaptations 0-1
+        fs, s, track = load_signal("sa19")
+        sample = "SA19.WAV, adaptations 0-1"
+        max_adpt = 1
+    else:                                    # the workload's generator run for a shorter signal (same seed, same law,
+        fs, track = load_track(workload)     # same margins), pitch grid = the head of the workload's
+        dur, max_adpt = (2.5, 1) if fs == 16000 else (0.35, 0)     # 48 kHz: ~25 frames/s on a CPU
+        s = synth_speech_int16(dur, fs) / 32768.0
+        sample = "%.2f s of the workload's synthetic signal, adaptations 0-%d" % (dur, max_adpt)
+    grid = O.get_linear(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    ti5, sp, vo, fstep = O.voiced_unvoiced_frames(s, fs, "female")
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(host, 16)       # the GPU box's CPU share per GPU; beyond it the small BLAS calls only contend
+    runs = {}
+    for threads in (1, cores):
+        with threadpool_limits(limits=threads):
+            t0 = time.time()
+            r = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=160, maxAdpt=max_adpt)
+            dt = time.time() - t0
+        runs[threads] = (r["n_ls_frames"] / dt, dt, r)
+    best = max(runs, key=lambda k: runs[k][0])
+    return {"value": runs[best][0], "unit": "frames/s", "cores": best, "kind": "port",
+            "frames_per_s_1_thread": runs[1][0], "frames_per_s_%d_threads" % cores: runs[cores][0], "host_cores": host,
+            "sample": "%s (%d LS frames; %.1f s at 1 BLAS thread, %.1f s at %d), oracle/eaqhm_oracle.py"
+                      % (sample, runs[1][2]["n_ls_frames"], runs[1][1], runs[cores][1], cores),
+            "srer_db": [float(v) for v in runs[best][2]["SRER"]]}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (nothing in this process
+    has touched a GPU yet) and pass rank 0's JSON line through."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def main():
@@ -86,9 +141,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--max-adpt", type=int, default=5)
-    ap.add_argument("--reps", type=int, default=0, help="tile SA19 this many times (default: --gpus)")
+    ap.add_argument("--workload", default="synth16k_60s", choices=WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE JSON line: everything else (RCCL prints a version banner to stdout) goes to stderr
     sys.stdout.flush()
@@ -100,10 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -115,8 +170,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from eaqhm_amd.engine import DeviceAnalysis, FramePlan, Sharding
-    reps = args.reps or args.gpus
-    fs, s, grid, frames, fstep = load_workload(reps)
+    fs, s, grid, frames, fstep = load_workload(args.workload)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
     shard = Sharding(rank, world, dist.group.WORLD if use_dist else None)
     eng = DeviceAnalysis(s, s, plan, 160, args.max_adpt, device_index=local, shard=shard)
@@ -141,57 +195,75 @@ def main():
         frames_done += eng.n_ls_frames
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(frames_done)], dtype=torch.float64, device="cuda")
-    if use_dist:
-        tmax = tt[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt[1:].clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, frames_total = float(tmax.item()), float(tsum.item())
-    else:
-        frames_total = float(frames_done)
-    srer = [float(v) for v in eng.SRER]
 
-    # ---- roofline of the dominant kernel (eaqhm_ls_kernel), from the events of the timed region
+    # ---- per-rank figures from the events of the timed region (LS launches on the launch stream)
     torch.cuda.synchronize()
     ls_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "ls"]
     post_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "post"]
     gather_ms = [e0.elapsed_time(e1) for (a, st, e0, e1) in eng.timeline if st == "gather"]
     N = 2 * plan.frame_wl[eng.f_lo:eng.f_hi].astype(np.int64) + 1
-    flops_per_launch = [float(ls_flops(N, 2 * plan.frame_K[eng.f_lo:eng.f_hi].astype(np.int64) + 1).sum())]
-    for nc in eng.ncol_hist[:max(n_adpt - 1, 0)]:
-        flops_per_launch.append(float(ls_flops(N, 2 * nc.cpu().numpy().astype(np.int64) + 1).sum()))
-    launches_per_step = len(flops_per_launch)
+    n_act = [plan.frame_K[eng.f_lo:eng.f_hi].astype(np.int64)]          # adaptation 0: K harmonics
+    for nc in eng.ncol_hist[:max(n_adpt - 1, 0)]:                         # adaptations >= 1: active slots per frame
+        n_act.append(nc.cpu().numpy().astype(np.int64))
+    flops_per_launch = [float(ls_flops(N, 2 * n + 1).sum()) for n in n_act]
+    # algorithmic bytes per launch: 8N signal window + 16 N n_active track windows (a >= 1) +
+    # 32 Kc amplitudes and slopes out
+    bytes_per_launch = [float(np.sum(8 * N) + (np.sum(16 * N * n) if a > 0 else 0) + np.sum(32 * (2 * n + 1)))
+                        for a, n in enumerate(n_act)]
     flops_step = sum(flops_per_launch)
-    ls_total_s = sum(ls_ms) / 1e3
-    achieved = flops_step * args.steps / ls_total_s / 1e12 if ls_total_s > 0 else 0.0
+    mine = torch.tensor([dt, float(frames_done), sum(ls_ms) / 1e3, flops_step * args.steps,
+                         float(np.mean(ls_ms)) if ls_ms else 0.0, float(eng.nf)], dtype=torch.float64, device="cuda")
+    if use_dist:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+    else:
+        allr = mine.cpu().numpy()[None, :]
+    dt = float(allr[:, 0].max())
+    frames_total = float(allr[:, 1].sum())
+    # roofline of the dominant kernel: algorithmic flops of ALL ranks' launches / (sum of their durations / ranks),
+    # i.e. per-GPU achieved rate averaged over the ranks
+    ls_total_s = float(allr[:, 2].sum())
+    achieved = float(allr[:, 3].sum()) / ls_total_s / 1e12 if ls_total_s > 0 else 0.0
+    srer = [float(v) for v in eng.SRER]
+    kernel = "eaqhm_ls_tile_kernel" if fs <= 16000 else "eaqhm_ls_mfma_kernel"
     # HBM traffic of that kernel: not measurable from inside this process; taken from the committed rocprofv3 PMC
-    # passes of this same command (profiles/r01_final/pmc_hbm_traffic.json), N=1 workload only
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm_traffic.json")
-    if world == 1 and reps == 1 and os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("eaqhm_ls_tile_kernel", {}).get("hbm_bytes_per_launch_fetch_doubled")
-    roofline = {"bound": "mfma", "kernel": "eaqhm_ls_tile_kernel", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
+    # passes of this same command and workload (profiles/r02_<workload>/pmc_hbm_traffic.json), N = 1 only
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_%s" % args.workload, "pmc_hbm_traffic.json")
+    if world == 1 and os.path.exists(pmc):
+        j = json.load(open(pmc))
+        traffic = j.get(kernel, {}).get("hbm_bytes_per_launch_fetch_doubled")
+        traffic_src = {"file": os.path.relpath(pmc, ROOT), "git_head": j.get("git_head")}
+    roofline = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final)",
-                "algorithmic_bytes_per_launch": float(np.sum(8 * N) + 32 * np.sum(2 * plan.frame_K[eng.f_lo:eng.f_hi] + 1)),
-                "flops_per_launch_mean": flops_step / max(launches_per_step, 1),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
+                "algorithmic_bytes_launch0": bytes_per_launch[0],
+                "flops_per_launch_mean": flops_step / max(len(flops_per_launch), 1),
                 "launch_ms_mean": float(np.mean(ls_ms)) if ls_ms else None,
                 "launches_timed": len(ls_ms),
                 "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None,
-                "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None}
+                "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None,
+                "ls_ms_mean_per_rank": [float(v) for v in allr[:, 4]],
+                "ls_frames_per_rank": [int(v) for v in allr[:, 5]],
+                "ls_imbalance_max_over_mean": float(allr[:, 4].max() / allr[:, 4].mean()) if allr[:, 4].mean() > 0 else None}
 
     out = {"metric": "analysis_frames_per_sec", "value": frames_total / dt, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-           "data": "SA19.WAV (the reference's sample recording) tiled x%d; pitch track = fixture from the "
-                   "reference's SWIPE'" % reps,
-           "config": {"workload": "sa19x%d_female_maxAdpt%d" % (reps, args.max_adpt), "samples": int(plan.L),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": ("synthetic speech-like signal (eaqhm_amd/synth.py, SURVEY §8d config 4 recipe)"
+                    if args.workload.startswith("synth") else "SA19.WAV (the reference's sample recording)")
+                   + "; pitch grid = fixture from the reference's SWIPE'",
+           "config": {"workload": "%s_female_maxAdpt%d" % (args.workload, args.max_adpt), "samples": int(plan.L),
                       "fs": int(fs), "ls_frames_per_adaptation": int(plan.n_frames), "adaptations_executed": n_adpt,
-                      "Kmax": int(plan.Kmax), "parallelism": "frames sharded x%d, all-gather of boundary records per adaptation" % world},
+                      "Kmax": int(plan.Kmax),
+                      "parallelism": "instants sharded x%d by LS cost; boundary records all-gathered per adaptation"
+                                     % world},
            "final_srer_db": max(srer), "srer_db": srer, "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(args.workload)
     else:
         out["cpu_baseline"] = None
     sys.stdout.flush()

@@ -14,6 +14,10 @@ extern "C" int eaqhm_ctx_create(eaqhm_ctx** out, int device) {
   c->n_cu = p.multiProcessorCount;
   c->lds_bytes = (int)p.sharedMemPerBlock;
   c->clock_khz = p.clockRate;
+  if (hipMalloc((void**)&c->faults, 64) != hipSuccess || hipMemset(c->faults, 0, 64) != hipSuccess) {
+    delete c;
+    return EAQHM_ENOMEM;
+  }
   *out = c;
   return EAQHM_OK;
 }
@@ -24,6 +28,7 @@ extern "C" int eaqhm_ctx_destroy(eaqhm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->scratch);
   }
+  if (ctx->faults) (void)hipFree(ctx->faults);
   delete ctx;
   return EAQHM_OK;
 }
@@ -42,6 +47,14 @@ extern "C" int eaqhm_sync(eaqhm_ctx* ctx) {
 
 extern "C" const char* eaqhm_last_error(eaqhm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+extern "C" int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t* h_count) {
+  if (!ctx || !h_count) return EAQHM_EINVAL;
+  HIP_TRY(ctx, hipMemcpyAsync(h_count, ctx->faults, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->faults, 0, sizeof(int32_t), ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return EAQHM_OK;
+}
+
 extern "C" int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]) {
   if (!ctx || !h_info) return EAQHM_EINVAL;
   h_info[0] = ctx->n_cu;
@@ -53,7 +66,7 @@ extern "C" int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]) {
 
 extern "C" int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value) {
   if (!ctx) return EAQHM_EINVAL;
-  if (key == EAQHM_OPT_LS_VARIANT && (value >= 1 && value <= 3)) {
+  if (key == EAQHM_OPT_LS_VARIANT && (value == 2 || value == 3)) {
     ctx->ls_variant = value;
     return EAQHM_OK;
   }

@@ -8,7 +8,7 @@
 
 #include "../../include/eaqhm_hip.h"
 
-#define EAQHM_ABI_VERSION 1
+#define EAQHM_ABI_VERSION 2
 
 struct eaqhm_ctx {
   int device = 0;
@@ -16,10 +16,11 @@ struct eaqhm_ctx {
   int n_cu = 0;
   int lds_bytes = 0;
   int clock_khz = 0;
-  int ls_variant = 3;  // 1: VALU Gramian (any size), 2: MFMA Gramian + tile Cholesky through memory, 3: all-on-chip tiles (+2 for big frames)
+  int ls_variant = 3;  // 2: MFMA Gramian + tile Cholesky through memory (any size), 3: all-on-chip tiles (+2 for big frames)
   int dbg_keep = 0;    // 1: in-kernel phase stamps on, accumulated across launches (diagnostics only)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  int* faults = nullptr;   // device counter: LS systems whose Cholesky pivot collapsed (singular normal matrix)
   char err[512] = {0};
 
   int fail(int code, const char* msg) {

@@ -404,7 +404,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
 
 // partials of `group` consecutive blocks are added first, so that the result does not depend on the block size
 extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double* partials, long long nblocks, int group,
-                                                                    double n, double std_det, double* sums_out) {
+                                                                    double n, double std_det, double* sums_out,
+                                                                    int* faults) {
   __shared__ double red[8];
   double a = 0, b = 0;
   const long long ngroups = (nblocks + group - 1) / group;
@@ -426,6 +427,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double
     double var = b / n - mean * mean;
     sums_out[0] = a; sums_out[1] = b; sums_out[2] = n;
     sums_out[3] = 20.0 * log10(std_det / sqrt(var));
+    sums_out[4] = (double)*faults;   // LS systems with a collapsed pivot in this adaptation (eaqhm_ls_faults)
+    *faults = 0;
   }
 }
 
@@ -538,7 +541,7 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK, NR);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, 256 / TBS,
-                     (double)(s_hi - s_lo), std_det, sums_out);
+                     (double)(s_hi - s_lo), std_det, sums_out, ctx->faults);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

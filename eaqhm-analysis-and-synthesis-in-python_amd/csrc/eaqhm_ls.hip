@@ -1,7 +1,8 @@
 // eaqhm_ls.hip — per-frame weighted complex least squares of the eaQHM analysis, batched over frames.
 // gfx950 (MI355X) only.  FP64 throughout: the reference is float64/complex128 (functions.py:420-535).
 //
-// One workgroup owns one frame at a time (persistent grid-stride over frames) and runs four phases:
+// One workgroup owns one frame at a time (frames pulled from per-class atomic queues) and runs four phases
+// (eaqhm_ls_tile.hip for frames whose system fits the register file, eaqhm_ls_mfma.hip for larger ones):
 //   A  basis      window the tracks of the active slots, bridge zero gaps, running-sum phases,
 //                 E2 = (am+eps)/(am_mid+eps) * exp(j*2*pi*F/fs); negative/DC/positive column layout
 //                 (functions.py:244-292, :508-519; adaptation 0: functions.py:444-455)
@@ -24,33 +25,7 @@ bool ls_tile_applicable(int Kcmax, int Nmax);
 
 
 // ------------------------------------------------------------------------------------------------
-// scratch carve-up (doubles) for one workgroup
-struct LsScratch {
-  double* Q;    // (Nmax+1) * nmax   running sums relative to the window middle, row u+1 <-> sample u
-  double* r;    // (Nmax+1) * nmax   amplitude ratios
-  double* Xre;  // Nmax * C1max      basis, [t][col], col fastest; C1 = Kc + 1 (signal column last)
-  double* Xim;
-  double* Lt;   // (Mmax) * (Mmax+1) * 2   transposed system matrix: Lt[k][i] = R[i][k], i in [k, M]
-};
-
-__host__ __device__ inline size_t ls_scratch_doubles(int nmax, int Nmax, int Kcmax) {
-  size_t C1 = (size_t)Kcmax + 1, M = 2 * (size_t)Kcmax;
-  return 2 * (size_t)(Nmax + 1) * nmax + 2 * (size_t)Nmax * C1 + 2 * M * (M + 1);
-}
-
-__device__ inline LsScratch carve(double* base, int nmax, int Nmax, int Kcmax) {
-  LsScratch s;
-  size_t C1 = (size_t)Kcmax + 1;
-  s.Q = base;
-  s.r = s.Q + (size_t)(Nmax + 1) * nmax;
-  s.Xre = s.r + (size_t)(Nmax + 1) * nmax;
-  s.Xim = s.Xre + (size_t)Nmax * C1;
-  s.Lt = s.Xim + (size_t)Nmax * C1;
-  return s;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Phase B: Gramian of the augmented basis -> transposed system matrix Lt (row k holds column k of R,
+// explicit-matrix seam, phase B: Gramian of the augmented basis -> transposed system matrix Lt (row k holds column k of R,
 // entries i = k..M, row stride ldl complex).  One thread per (a, b) pair, a >= b, of the C1 columns.
 __device__ void gram_to_system(const double* __restrict__ Xre, const double* __restrict__ Xim, int N, int Kc,
                                int ldx, const double* __restrict__ ww, double mid, double* __restrict__ Lt,
@@ -93,87 +68,6 @@ __device__ void gram_to_system(const double* __restrict__ Xre, const double* __r
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_kernel(LsArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  LsScratch S = carve(A.scratch + (size_t)blockIdx.x * A.scratch_stride, A.nmax, A.Nmax, A.Kcmax);
-  const int Mmax = 2 * A.Kcmax;
-  double* ww = lds;                 // Nmax
-  double* rowj = ww + A.Nmax;       // 2*Mmax
-  double* xs = rowj + 2 * Mmax;     // 2*Mmax
-  double* rho = xs + 2 * Mmax;      // 2*nmax
-  double* sh = rho + 2 * A.nmax;    // 8
-  const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
-
-  for (int f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
-    const int c = A.frame_c[f], wl = A.frame_wl[f], inst = A.frame_inst[f];
-    const int N = 2 * wl + 1, mid = wl;
-    const int n = (A.mode == 0) ? A.frame_K[f] : A.ncol[f];
-    const int Kc = 2 * n + 1, C1 = Kc + 1, M = 2 * Kc;
-    const int ldx = C1, ldl = M + 1;
-    const double f0 = (A.mode == 0) ? A.frame_f0[f] : A.f0_stale;
-    const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
-
-    // ---------------- Phase A ----------------
-    for (int u = tid; u < N; u += nt) {
-      double w = window_value(A.mode == 0, u, N);
-      ww[u] = w * w;
-      S.Xre[(size_t)u * ldx + n] = 1.0;   // DC column
-      S.Xim[(size_t)u * ldx + n] = 0.0;
-      S.Xre[(size_t)u * ldx + Kc] = A.s[(size_t)(c - wl) + u];  // signal column
-      S.Xim[(size_t)u * ldx + Kc] = 0.0;
-    }
-    if (A.mode == 1) {
-      fill_columns(A, S.Q, S.r, rho, mycols, n, N, mid, c, wl, seeds);
-      __syncthreads();
-      // A3: one sincos per (sample, positive column); it feeds the positive column at u and the
-      // negative column at N-2-u (time-reversed, functions.py:284-285)
-      const int items = (N + 1) * n;
-      for (int idx = tid; idx < items; idx += nt) {
-        int u = idx / n - 1, j = idx - (u + 1) * n;
-        double q = S.Q[(size_t)(u + 1) * n + j];
-        double sn, cs;
-        sincos((2.0 * M_PI * q) / A.fs, &sn, &cs);
-        if (u >= 0) {
-          double rr = S.r[(size_t)u * n + j];
-          S.Xre[(size_t)u * ldx + n + 1 + j] = rr * cs;
-          S.Xim[(size_t)u * ldx + n + 1 + j] = rr * sn;
-        }
-        if (u <= N - 2) {
-          int t = N - 2 - u;
-          double rr = S.r[(size_t)(u + 1) * n + j];
-          double pr = rho[2 * j], pi = rho[2 * j + 1];
-          S.Xre[(size_t)t * ldx + j] = rr * (cs * pr - sn * pi);
-          S.Xim[(size_t)t * ldx + j] = rr * (cs * pi + sn * pr);
-        }
-      }
-    } else {
-      // adaptation 0: E0[n,k] = exp(j*2*pi*k*f0*n/fs) (functions.py:453-454); negative = conjugate
-      const int items = N * n;
-      for (int idx = tid; idx < items; idx += nt) {
-        int u = idx / n, j = idx - u * n;
-        double fk = (double)(j + 1) * f0;
-        double nn = (double)(u - mid);
-        double sn, cs;
-        sincos((nn * 2.0 * M_PI * fk) / A.fs, &sn, &cs);
-        S.Xre[(size_t)u * ldx + n + 1 + j] = cs;
-        S.Xim[(size_t)u * ldx + n + 1 + j] = sn;
-        S.Xre[(size_t)u * ldx + j] = cs;
-        S.Xim[(size_t)u * ldx + j] = -sn;
-      }
-    }
-    __syncthreads();
-
-    // ---------------- Phase B / C ----------------
-    gram_to_system(S.Xre, S.Xim, N, Kc, ldx, ww, (double)mid, S.Lt, ldl);
-    __syncthreads();
-    cholesky_solve(S.Lt, M, ldl, rowj, xs, sh);
-
-    // ---------------- Phase D ----------------
-    write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // adaptation >= 1 frame set-up (functions.py:202-213): active slots + empty-row seeding flags
 // One wave per frame: lanes test 64 slots at a time, the ballot gives count and compacted positions.
@@ -206,7 +100,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_frame_prep_kernel(const 
 // explicit-matrix seam (one frame): eaqhmLS_complexamps / iqhmLS_complexamps as Python-level functions
 struct LsExplicitArgs {
   const double* s; int N; const double* am; const double* fm; const double* f0range; int Kc;
-  const double* window; double fs; double* out_amp; double* out_slope; double* scratch;
+  const double* window; double fs; double* out_amp; double* out_slope; double* scratch; int* fault;
 };
 
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_explicit_kernel(LsExplicitArgs A) {
@@ -260,7 +154,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_explicit_kernel(LsExp
   __syncthreads();
   gram_to_system(Xre, Xim, N, Kc, ldx, ww, midf, Lt, ldl);
   __syncthreads();
-  cholesky_solve(Lt, M, ldl, rowj, xs, sh);
+  cholesky_solve(Lt, M, ldl, rowj, xs, sh, A.fault);
   for (int q = tid; q < 2 * Kc; q += nt) {
     A.out_amp[q] = xs[q];
     A.out_slope[q] = xs[2 * Kc + q];
@@ -307,67 +201,47 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   if (n_frames == 0) return EAQHM_OK;
   if (wl_max <= 0) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: wl_max must be positive");
   const int nmax = Kmax, Nmax = 2 * wl_max + 1, Kcmax = 2 * Kmax + 1;
-  if (ctx->ls_variant >= 2) {
-    LsArgs B;
-    B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.am_cur = am_cur; B.fm_cur = fm_cur; B.Kmax = Kmax;
-    B.frame_inst = frame_inst; B.frame_c = frame_c; B.frame_wl = frame_wl; B.frame_f0 = frame_f0; B.frame_K = frame_K;
-    B.ncol = ncol; B.cols = cols; B.seeded = seeded; B.any_seed = any_seed; B.n_frames = n_frames; B.a_iter = a_iter;
-    B.f0_stale = f0_stale; B.f0min = f0min; B.records = records; B.raw_amp = raw_amp; B.raw_slope = raw_slope;
-    B.nmax = nmax; B.Nmax = Nmax; B.Kcmax = Kcmax;
-    int grid = ctx->n_cu < n_frames ? ctx->n_cu : n_frames;
-    const size_t st_m = ls_mfma_scratch_stride(nmax, Nmax, Kcmax), st_t = ls_tile_scratch_stride(nmax, Nmax);
-    const size_t frame_bytes = (st_m > st_t ? st_m : st_t) * grid * sizeof(double);
-    const int zchunks = (int)((L + 1023) >> 10);
-    const size_t zloc_bytes = (((size_t)Kmax * L * sizeof(unsigned short)) + 255) & ~(size_t)255;
-    const size_t ztot_bytes = (((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255;
-    const size_t flag_bytes = zloc_bytes + ztot_bytes + (((size_t)zchunks + 255) & ~(size_t)255);
-    const size_t cls_bytes = ((16 + (size_t)6 * n_frames) * sizeof(int) + 255) & ~(size_t)255;
-    int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
-    if (rc) return rc;
-    B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes);
-    B.ztot = (const int*)((char*)ctx->scratch + frame_bytes + zloc_bytes);
-    B.zchunks = zchunks;
-    B.zflag = (unsigned char*)ctx->scratch + frame_bytes + zloc_bytes + ztot_bytes;
-    {   // chunk flags and the class header right behind them: one clear for both
-      const size_t zflag_bytes = flag_bytes - zloc_bytes - ztot_bytes;
-      HIP_TRY(ctx, hipMemsetAsync(B.zflag, 0, zflag_bytes + 16 * sizeof(int), ctx->stream));
-    }
-    B.cls = (int*)((char*)ctx->scratch + frame_bytes + flag_bytes);
-    int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
-    const bool tile_path = ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax);
-    if (!tile_path)   // the frame queue of the fallback kernel when it takes every frame
-      HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
-    B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
-    B.scratch = (double*)ctx->scratch;
-    int min_nb = 0;
-    if (tile_path) {   // small frames: everything in registers/LDS; the rest falls through
-      B.scratch_stride = st_t; B.work_counter = counters + 2;
-      rc = launch_ls_tile(ctx, B, grid);
-      if (rc) return rc;
-      min_nb = 1;
-      if ((2 * Kcmax + 1 + 15) / 16 <= 13) return EAQHM_OK;   // no frame can be larger: skip the second launch
-    }
-    B.scratch_stride = st_m; B.work_counter = counters + 1;
-    return launch_ls_mfma(ctx, B, grid, min_nb);
-  }
-  const size_t stride = (ls_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
-  int grid = ctx->n_cu * 2;
-  if (grid > n_frames) grid = n_frames;
-  int rc = ctx->reserve(stride * grid * sizeof(double));
+  LsArgs B;
+  B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.am_cur = am_cur; B.fm_cur = fm_cur; B.Kmax = Kmax;
+  B.frame_inst = frame_inst; B.frame_c = frame_c; B.frame_wl = frame_wl; B.frame_f0 = frame_f0; B.frame_K = frame_K;
+  B.ncol = ncol; B.cols = cols; B.seeded = seeded; B.any_seed = any_seed; B.n_frames = n_frames; B.a_iter = a_iter;
+  B.f0_stale = f0_stale; B.f0min = f0min; B.records = records; B.raw_amp = raw_amp; B.raw_slope = raw_slope;
+  B.nmax = nmax; B.Nmax = Nmax; B.Kcmax = Kcmax; B.fault = ctx->faults;
+  int grid = ctx->n_cu < n_frames ? ctx->n_cu : n_frames;
+  const size_t st_m = ls_mfma_scratch_stride(nmax, Nmax, Kcmax), st_t = ls_tile_scratch_stride(nmax, Nmax);
+  const size_t frame_bytes = (st_m > st_t ? st_m : st_t) * grid * sizeof(double);
+  const int zchunks = (int)((L + 1023) >> 10);
+  const size_t zloc_bytes = (((size_t)Kmax * L * sizeof(unsigned short)) + 255) & ~(size_t)255;
+  const size_t ztot_bytes = (((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255;
+  const size_t flag_bytes = zloc_bytes + ztot_bytes + (((size_t)zchunks + 255) & ~(size_t)255);
+  const size_t cls_bytes = ((16 + (size_t)6 * n_frames) * sizeof(int) + 255) & ~(size_t)255;
+  int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
   if (rc) return rc;
-  LsArgs A;
-  A.mode = mode; A.s = s; A.L = L; A.fs = fs; A.am_cur = am_cur; A.fm_cur = fm_cur; A.Kmax = Kmax;
-  A.frame_inst = frame_inst; A.frame_c = frame_c; A.frame_wl = frame_wl; A.frame_f0 = frame_f0; A.frame_K = frame_K;
-  A.ncol = ncol; A.cols = cols; A.seeded = seeded; A.any_seed = any_seed; A.n_frames = n_frames; A.a_iter = a_iter;
-  A.f0_stale = f0_stale; A.f0min = f0min; A.records = records; A.raw_amp = raw_amp;
-  A.raw_slope = raw_slope; A.scratch = (double*)ctx->scratch; A.scratch_stride = stride; A.nmax = nmax; A.Nmax = Nmax;
-  A.Kcmax = Kcmax; A.work_counter = nullptr; A.debug = nullptr; A.zloc = nullptr; A.ztot = nullptr; A.zchunks = 0; A.zflag = nullptr; A.cls = nullptr;
-  size_t lds_bytes = ((size_t)Nmax + 4 * (size_t)(2 * Kcmax) + 2 * (size_t)nmax + 8) * sizeof(double);
-  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for LDS staging");
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(eaqhm_ls_kernel, dim3(grid), dim3(256), lds_bytes, ctx->stream, A);
-  HIP_TRY(ctx, hipGetLastError());
-  return EAQHM_OK;
+  B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes);
+  B.ztot = (const int*)((char*)ctx->scratch + frame_bytes + zloc_bytes);
+  B.zchunks = zchunks;
+  B.zflag = (unsigned char*)ctx->scratch + frame_bytes + zloc_bytes + ztot_bytes;
+  {   // chunk flags and the class header right behind them: one clear for both
+    const size_t zflag_bytes = flag_bytes - zloc_bytes - ztot_bytes;
+    HIP_TRY(ctx, hipMemsetAsync(B.zflag, 0, zflag_bytes + 16 * sizeof(int), ctx->stream));
+  }
+  B.cls = (int*)((char*)ctx->scratch + frame_bytes + flag_bytes);
+  int* counters = (int*)((char*)ctx->scratch + ctx->scratch_bytes - 256);
+  const bool tile_path = ctx->ls_variant == 3 && ls_tile_applicable(Kcmax, Nmax);
+  if (!tile_path)   // the frame queue of the large-frame kernel when it takes every frame
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
+  B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
+  B.scratch = (double*)ctx->scratch;
+  int min_nb = 0;
+  if (tile_path) {   // small frames: everything in registers/LDS; the rest falls through
+    B.scratch_stride = st_t; B.work_counter = counters + 2;
+    rc = launch_ls_tile(ctx, B, grid);
+    if (rc) return rc;
+    min_nb = 1;
+    if ((2 * Kcmax + 1 + 15) / 16 <= 13) return EAQHM_OK;   // no frame can be larger: skip the second launch
+  }
+  B.scratch_stride = st_m; B.work_counter = counters + 1;
+  return launch_ls_mfma(ctx, B, grid, min_nb);
 }
 
 extern "C" int eaqhm_ls_explicit(eaqhm_ctx* ctx, const double* s, int32_t N, const double* am, const double* fm,
@@ -384,7 +258,7 @@ extern "C" int eaqhm_ls_explicit(eaqhm_ctx* ctx, const double* s, int32_t N, con
   size_t doubles = 2 * (size_t)N * C1 + 2 * M * (M + 1);
   int rc = ctx->reserve(doubles * sizeof(double));
   if (rc) return rc;
-  LsExplicitArgs A{s, N, am, fm, f0range, Kc, window, fs, out_amp, out_slope, (double*)ctx->scratch};
+  LsExplicitArgs A{s, N, am, fm, f0range, Kc, window, fs, out_amp, out_slope, (double*)ctx->scratch, ctx->faults};
   size_t lds_bytes = ((size_t)N + 4 * M + 8) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_explicit: problem too large");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_explicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

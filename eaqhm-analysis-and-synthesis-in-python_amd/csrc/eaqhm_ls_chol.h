@@ -24,7 +24,14 @@ __device__ inline void diag_init(double* Z, int tid) {
   if (g == 1) { Z[2 * (i * DG_LD + k)] = (i == k) ? 1.0 : 0.0; Z[2 * (i * DG_LD + k) + 1] = 0.0; }
 }
 
-__device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid) {
+// Singular systems: position q of the tile is a real unknown when q < nvalid (the others are the right-hand-side
+// position or identity padding).  dref[q] is the ORIGINAL diagonal entry of the system at that position; a pivot
+// (the squared diagonal of L) that has collapsed to <= PIVOT_TOL of it means the column is a combination of earlier
+// ones — the reference's inv() raises LinAlgError there (functions.py:465, :530).  One thread watches the pivots
+// and counts the frame in *fault (eaqhm_ls_faults).
+#define PIVOT_TOL 1e-12
+__device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid,
+                                 const double* dref, int nvalid, int* fault) {
   // 2x2 block pivots: seven elimination steps instead of fifteen.  With P = [[p, conj(q)], [q, r]] the pivot block
   // of columns (j, j+1) and a = D[i][j..j+1], b = D[k][j..j+1]:   D[i][k] -= a P^-1 b^H   (i >= k >= j+2), and
   // the rows of the inverse below the block follow the same elimination on [L | I].  Columns / rows inside a
@@ -38,9 +45,13 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
     if (work) {
       double p = D[2 * (j * DG_LD + j)], r = D[2 * ((j + 1) * DG_LD + j + 1)];
       const double qr = D[2 * ((j + 1) * DG_LD + j)], qi = D[2 * ((j + 1) * DG_LD + j) + 1];
-      p = (p > 0.0) ? p : 1.0;
       double det = p * r - (qr * qr + qi * qi);
-      det = (det > 0.0) ? det : 1.0;   // only the RHS position of the last tile can get here (residual ~ 0)
+      if (e == 255 && g == 0) {   // (this thread works in every step)
+        if ((j < nvalid && !(p > PIVOT_TOL * dref[j])) || (j + 1 < nvalid && !(det > PIVOT_TOL * dref[j + 1] * p)))
+          atomicAdd(fault, 1);
+      }
+      p = (p > 0.0) ? p : 1.0;
+      det = (det > 0.0) ? det : 1.0;   // legitimately only at the RHS position of the last tile (residual ~ 0)
       double dinv = __builtin_amdgcn_rcp(det);
       dinv = dinv * fma(-det, dinv, 2.0);
       dinv = dinv * fma(-det, dinv, 2.0);
@@ -70,6 +81,10 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
     const int pj = ((g == 0) ? k : i) & ~1;    // first column (D) / row (Z) of the entry's pivot block
     double p = D[2 * (pj * DG_LD + pj)], r = D[2 * ((pj + 1) * DG_LD + pj + 1)];
     const double qr = D[2 * ((pj + 1) * DG_LD + pj)], qi = D[2 * ((pj + 1) * DG_LD + pj) + 1];
+    if (e == 255 && g == 0) {   // the last pivot block (14, 15) is not covered by the elimination steps
+      const double s = r - (qr * qr + qi * qi) / p;
+      if ((14 < nvalid && !(p > PIVOT_TOL * dref[14])) || (15 < nvalid && !(s > PIVOT_TOL * dref[15]))) atomicAdd(fault, 1);
+    }
     p = (p > 0.0) ? p : 1.0;
     double i11 = __builtin_amdgcn_rsq(p);
     i11 = i11 * fma(-0.5 * p * i11, i11, 1.5);
@@ -134,11 +149,11 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
 #define CH_MB 6          // tiles per wave, column and register group
 #define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
-#define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32)
+#define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32 + 16)
 
 // T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
 __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, int nt, int Kc, int nbk,
-                                            double* lds, double* xs) {
+                                            double* lds, double* xs, int* fault) {
   const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* Dc = lds;
@@ -150,6 +165,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
   double* trb = LdI + TL_TILE + (size_t)wave * 2 * TL_TILE;   // this wave's transposition buffer
   double* zv = LdI + TL_TILE + 8 * 2 * TL_TILE;
   double* xv = zv + 2 * 16 * CH_NTMAX;
+  double* dref = xv + 32;   // original diagonal of the tile column being factorised
 
   for (int Q = 0; Q < nt; ++Q) {
     // tiles P = Q + wave + 8 m of this column, in groups of CH_MB per wave (registers); the first group holds the
@@ -189,6 +205,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = (lq + 4 * r) * 16 + lcol;
+          if (P == Q && lq + 4 * r == lcol) dref[lcol] = Ct[o];
           const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
           const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
           p1[m][r] = cr; p3[m][r] = ci;
@@ -204,7 +221,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         }
         diag_init(Zc, tid);
         __syncthreads();
-        diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid);   // ends with a barrier
+        // the last tile row is the right-hand side (row 0) plus identity padding: no real unknown there
+        diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid, dref, (Q == nt - 1) ? 0 : 16, fault);   // ends with a barrier
         for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
       }
       // panel tiles: X = C W^H (three real products), stored k-major

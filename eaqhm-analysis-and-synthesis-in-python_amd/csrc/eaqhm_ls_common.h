@@ -25,6 +25,7 @@ struct LsArgs {
   // Classes 0-4 are the register budgets of eaqhm_ls_tile_kernel, class 5 is left to eaqhm_ls_mfma_kernel.
   int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
+  int* fault;                 // device counter of singular systems (eaqhm_ctx::faults)
 };
 
 // wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
@@ -160,7 +161,8 @@ __device__ inline void fill_columns(const LsArgs& A, double* Q, double* r, doubl
 // Phase C (round-1 form): left-looking complex Cholesky on transposed storage Lt[k][i] = R[i][k] (coalesced
 // over rows), the right-hand side carried as row M (so the forward solve comes for free), then back
 // substitution by wave 0.  Result x (M complex, interleaved) in LDS `xs`.
-__device__ inline void cholesky_solve(double* __restrict__ Lt, int M, int ldl, double* rowj, double* xs, double* sh) {
+__device__ inline void cholesky_solve(double* __restrict__ Lt, int M, int ldl, double* rowj, double* xs, double* sh,
+                                      int* fault) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int j = 0; j < M; ++j) {
     for (int k = tid; k < j; k += nt) {  // row j of L (entries k < j) -> LDS
@@ -180,6 +182,7 @@ __device__ inline void cholesky_solve(double* __restrict__ Lt, int M, int ldl, d
         ai -= li * cr - lr * ci;
       }
       if (i == j) {
+        if (!(ar > 1e-12 * Lt[oj])) { atomicAdd(fault, 1); ar = 1.0; }   // collapsed pivot: singular normal matrix
         double d = sqrt(ar);
         sh[0] = d;
         Lt[oj] = d; Lt[oj + 1] = 0.0;
@@ -230,10 +233,14 @@ __device__ inline void write_record(const LsArgs& A, const double* xs, double* s
                                     int inst, int c, double f0, bool seeds) {
   const int tid = threadIdx.x, nt = blockDim.x, Kc = 2 * n + 1;
   if (A.raw_amp) {
+    // in the order the seam functions return them.  Adaptation 0: f0range = (-K..K) f0 (functions.py:189), while the
+    // kernels keep the negative block as the conjugates of the positive one in ITS order: reversed on the way out.
+    // Adaptations >= 1: the negative block keeps the column order of the positive one (functions.py:284).
     const int stride = 2 * (2 * A.Kmax + 1);
     for (int q = tid; q < 2 * Kc; q += nt) {
-      A.raw_amp[(size_t)f * stride + q] = xs[q];
-      A.raw_slope[(size_t)f * stride + q] = xs[2 * Kc + q];
+      const int col = q >> 1, src = (A.mode == 0 && col < n) ? (n - 1 - col) : col;
+      A.raw_amp[(size_t)f * stride + q] = xs[2 * src + (q & 1)];
+      A.raw_slope[(size_t)f * stride + q] = xs[2 * Kc + 2 * src + (q & 1)];
     }
   }
   double amax = 0.0;  // amplitude floor over the positive slots (functions.py:309)

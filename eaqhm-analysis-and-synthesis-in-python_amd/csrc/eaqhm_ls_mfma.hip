@@ -247,7 +247,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     }
     __syncthreads();
 
-    tile_cholesky_memory(S.T, S.WT, ntl, Kc, nbk, Xre, xs);
+    tile_cholesky_memory(S.T, S.WT, ntl, Kc, nbk, Xre, xs, A.fault);
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
   }
 }

@@ -186,6 +186,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   double* sh = xs + 4 * uni(A.Kcmax);                // 16
   double* win = sh + 16;                             // [64*CI_NCH] analysis window of the frame
   double* sig = win + 64 * CI_NCH;                   // [64*CI_NCH] signal window of the frame
+  double* dorig = sig + 64 * CI_NCH;                 // [16*NT]     original diagonal of the system (singularity check)
 
   const int Npad = ((uni(A.Nmax) + 63) >> 6) << 6;
   double* Qs = uni(A.scratch) + (size_t)blockIdx.x * (size_t)uni((int)A.scratch_stride);  // bridged fm[j][t]
@@ -433,6 +434,13 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           }
         }
       }
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {   // original diagonal entries, for the collapsed-pivot check of diag_coop
+        if (!live[sl] || tP[sl] != tQ[sl]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (lq + 4 * r == lcol) dorig[16 * tP[sl] + lcol] = accR[sl][r];
+      }
       for (int jb = 0; jb < nt; ++jb) {
         const int xd = jb * (jb + 1) / 2 + jb;
         if (wave == (xd % TL_CW)) {  // publish the diagonal tile: Dc[row][col] = T[row][col]
@@ -450,7 +458,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         diag_init(Zc, tid);
         __syncthreads();  // (A) diagonal tile published, inverse initialised
         STAMP(6);
-        diag_coop(Dc, Zc, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, tid);  // ends with a barrier
+        // real unknowns: every position but, in the last tile, the signal column `is` and the padding behind it
+        diag_coop(Dc, Zc, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, tid, dorig + 16 * jb,
+                  (jb == nt - 1) ? is : 16, uni(A.fault));  // ends with a barrier
         STAMP(10);
         // ---- panel tiles (P > jb, Q == jb): X = T W^H, published as Pan[P][k][row]
 #pragma unroll
@@ -661,7 +671,7 @@ static size_t tl_usize_c() {
 static size_t tl_usize_g(int TS, int ldx_max) { return (size_t)2 * TS * ldx_max + (size_t)CI_STRIDE * 52 + 52 * CI_NCH + 32; }
 static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
   const size_t c = tl_usize_c(), g = tl_usize_g(TS, ldx_max);
-  return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 2 * 64 * CI_NCH;
+  return (c > g ? c : g) + 4 * (size_t)Kcmax + 16 + 2 * 64 * CI_NCH + 16 * TL_NTMAX;
 }
 
 // the tile variant needs its LDS budget (which grows with Kmax through the solution vector) to fit

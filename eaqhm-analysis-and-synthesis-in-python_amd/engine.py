@@ -59,51 +59,82 @@ class FramePlan:
                 raise ValueError("an analysis window reaches outside the signal (analysisWindow too small)")
 
 
+def ls_cost(N, Kc):
+    """Algorithmic FP64 flops of one frame's least squares: Hermitian 3-block Gramian + right-hand
+    side + complex Cholesky + two triangular solves."""
+    N = np.asarray(N, dtype=np.float64)
+    Kc = np.asarray(Kc, dtype=np.float64)
+    return 12 * N * Kc * (Kc + 1) + 8 * N * Kc + (32.0 / 3.0) * Kc ** 3 + 32 * Kc ** 2
+
+
 class Sharding:
-    """Contiguous, equal-sized ranges of analysis instants per rank (the last ranks may be short or
-    empty); `group` is a torch.distributed process group or None for a single process."""
+    """Contiguous ranges of analysis instants per rank, balanced by the LS cost of their frames (SURVEY.md §8e:
+    "balanced by sum F(N,Kc), not by count": the cost of a frame varies ~2.5x with the pitch); `group` is a
+    torch.distributed process group or None for a single process.  Every rank derives the same bounds from the
+    same frame plan, so no communication is needed to agree on them."""
 
     def __init__(self, rank=0, world=1, group=None):
         self.rank, self.world, self.group = int(rank), int(world), group
         self.collective = group is not None      # a 1-rank group still goes through the collectives (rehearsal)
+        self.bounds = None
 
-    def chunk(self, n_instants):
-        return -(-n_instants // self.world)
+    def balance(self, n_instants, cost=None):
+        """Fix the instant ranges: bounds[r] .. bounds[r+1] is rank r's.  `cost` = per-instant LS cost (zero for the
+        instants that are not analysed); None or all-zero -> equal counts."""
+        T, W = int(n_instants), self.world
+        if cost is None or W == 1 or float(np.sum(cost)) <= 0.0:
+            c = -(-T // W)
+            b = [min(r * c, T) for r in range(W + 1)]
+        else:
+            cum = np.cumsum(np.asarray(cost, dtype=np.float64))
+            cuts = np.searchsorted(cum, cum[-1] * np.arange(1, W) / W, side="left") + 1
+            b = [0] + [int(min(v, T)) for v in cuts] + [T]
+            for r in range(1, W + 1):
+                b[r] = max(b[r], b[r - 1])
+        b[W] = T
+        self.bounds = b
+        return b
 
     def instants(self, n_instants, rank=None):
+        if self.bounds is None or self.bounds[-1] != n_instants:
+            self.balance(n_instants)
         r = self.rank if rank is None else rank
-        c = self.chunk(n_instants)
-        return min(r * c, n_instants), min((r + 1) * c, n_instants)
+        return self.bounds[r], self.bounds[r + 1]
 
     def _all_gather_into(self, out, part):
-        """out = concatenation over ranks of `part` (RCCL all-gather; `part` may be a slice of `out`)."""
+        """out = concatenation over ranks of `part` (RCCL all-gather of equal parts)."""
         import torch.distributed as dist
         dist.all_gather_into_tensor(out, part, group=self.group)
 
     def all_gather_rows(self, buf, n_instants):
-        """In-place all-gather: every rank contributes rows [rank*chunk, (rank+1)*chunk) of `buf`."""
+        """Every rank ends up with every rank's rows of `buf` (rank r owns rows bounds[r] .. bounds[r+1]).  The ranges
+        differ in length, so this is a sum over ranks of the buffer with the foreign rows zeroed — done once per run,
+        when the results are collected, or per adaptation only for inputs too short for the boundary exchange."""
         if not self.collective:
             return
-        c = self.chunk(n_instants)
-        self._all_gather_into(buf, buf[self.rank * c:(self.rank + 1) * c])
+        lo, hi = self.instants(n_instants)
+        buf[:lo].zero_()
+        buf[hi:].zero_()
+        self.all_reduce_sum(buf)
 
     def share_rows(self, buf, n_instants, margin):
         """What the interpolation of one rank's time range reads from the other ranks' rows of `buf`: the `margin`
         rows on either side of its own range and the first rows of the file (pad knots of short runs).  Every rank
         contributes the first and the last `margin` rows of its range to one small all-gather and copies its two
         neighbours' parts into place; the full rows are gathered once, when the results are collected
-        (all_gather_rows).  Falls back to the full all-gather when the ranges are shorter than the margin.
+        (all_gather_rows).  Falls back to the full exchange when some range is shorter than the margin.
         Returns True if only boundary rows were exchanged."""
         if not self.collective:
             return False
-        c = self.chunk(n_instants)
-        if margin < 4 or c < margin:
+        self.instants(n_instants)
+        b = self.bounds
+        if margin < 4 or min(b[r + 1] - b[r] for r in range(self.world)) < margin:
             self.all_gather_rows(buf, n_instants)
             return False
         import torch
         r, m = self.rank, margin
-        lo = r * c
-        part = torch.cat((buf[lo:lo + m], buf[lo + c - m:lo + c]))
+        lo, hi = b[r], b[r + 1]
+        part = torch.cat((buf[lo:lo + m], buf[hi - m:hi]))
         got = buf.new_empty((self.world * 2 * m, buf.shape[1]))
         self._all_gather_into(got, part)
         if r > 0:
@@ -112,7 +143,7 @@ class Sharding:
             if k > 0:
                 buf[0:k].copy_(got[0:k])
         if r < self.world - 1:
-            buf[lo + c:lo + c + m].copy_(got[(r + 1) * 2 * m:(r + 1) * 2 * m + m])     # right neighbour's first rows
+            buf[hi:hi + m].copy_(got[(r + 1) * 2 * m:(r + 1) * 2 * m + m])             # right neighbour's first rows
         return True
 
     def all_reduce_sum(self, t):
@@ -143,6 +174,9 @@ class DeviceAnalysis:
         self.RS = 3 * K + 1
         # this rank's instants, frames and time range
         sh = self.shard
+        cost = np.zeros(T)
+        cost[p.frame_inst] = ls_cost(2 * p.frame_wl.astype(np.int64) + 1, 2 * p.frame_K.astype(np.int64) + 1)
+        sh.balance(T, cost)
         self.i_lo, self.i_hi = sh.instants(T)
         mine = np.flatnonzero((p.frame_inst >= self.i_lo) & (p.frame_inst < self.i_hi))
         lo, hi = (int(mine[0]), int(mine[-1]) + 1) if len(mine) else (0, 0)
@@ -151,9 +185,9 @@ class DeviceAnalysis:
         def bound(r):
             if r <= 0:
                 return 0
-            if r >= sh.world or r * sh.chunk(T) >= T:
+            if r >= sh.world or sh.bounds[r] >= T:
                 return L
-            return r * sh.chunk(T) * p.step
+            return sh.bounds[r] * p.step
         self.s_lo, self.s_hi = bound(sh.rank), bound(sh.rank + 1)
         self.t_lo = max(0, self.s_lo - p.wl_max)
         self.t_hi = min(L, self.s_hi + p.wl_max)
@@ -188,14 +222,13 @@ class DeviceAnalysis:
         self.am_cur = torch.zeros(K, L, dtype=f64, device=dev)
         self.fm_cur = torch.zeros(K, L, dtype=f64, device=dev)
         # frame-centre records, double-buffered: [0] = adaptation in flight, [1] = last accepted
-        Tpad = sh.chunk(T) * sh.world
-        self.records = [torch.zeros(Tpad, self.RS, dtype=f64, device=dev) for _ in range(2)]
+        self.records = [torch.zeros(T, self.RS, dtype=f64, device=dev) for _ in range(2)]
         self.ph_knot = [torch.zeros(T, K, dtype=f64, device=dev) for _ in range(2)]
         self.s_hat = [torch.zeros(L, dtype=f64, device=dev) for _ in range(2)]
         self.code = torch.zeros(T, K, dtype=torch.uint8, device=dev)
         self.mom = torch.zeros(T, K + 1, dtype=f64, device=dev)
         self.partials = torch.zeros(self.ctx.eval_partials_len(0, L, p.step), dtype=f64, device=dev)
-        self.sums = torch.zeros(4, dtype=f64, device=dev)
+        self.sums = torch.zeros(8, dtype=f64, device=dev)    # {sum d, sum d^2, n, SRER dB, LS faults, -, -, -}
         self.raw = None
         if keep_raw:
             self.raw = (torch.zeros(max(self.nf, 1), 2 * (2 * K + 1), dtype=f64, device=dev),
@@ -258,16 +291,25 @@ class DeviceAnalysis:
             self.timeline.append((a, "post", e0, e1))
 
     def post_result(self):
-        """SRER of the adaptation enqueued last (host float): the one device->host read of an adaptation."""
+        """SRER of the adaptation enqueued last (host float): the one device->host read of an adaptation.  The same
+        read carries the count of singular LS systems of that adaptation; like the reference, whose inv() raises
+        there (functions.py:465, :530), the run aborts with numpy.linalg.LinAlgError."""
         p, sh = self.plan, self.shard
         if not sh.collective:
-            return float(self.sums[3].item())
-        red = self.sums[:2].clone()
-        sh.all_reduce_sum(red)
-        tot, tot2 = (float(v) for v in red.cpu())
-        n = float(p.L)
-        mean = tot / n
-        return float(20.0 * np.log10(self.std_det / np.sqrt(tot2 / n - mean * mean)))
+            srer, faults = (float(v) for v in self.sums[3:5].cpu())
+        else:
+            red = self.sums[[0, 1, 4]]
+            sh.all_reduce_sum(red)
+            tot, tot2, faults = (float(v) for v in red.cpu())
+            n = float(p.L)
+            mean = tot / n
+            srer = float(20.0 * np.log10(self.std_det / np.sqrt(tot2 / n - mean * mean)))
+        if faults > 0:
+            raise np.linalg.LinAlgError("Singular matrix (%d frame(s) of this adaptation: a collapsed Cholesky pivot "
+                                        "in the normal equations)" % int(faults))
+        if not np.isfinite(srer):
+            raise FloatingPointError("SRER of the adaptation is not finite (%r)" % srer)
+        return srer
 
     def post_stage(self, a):
         """Interpolation + synthesis + SRER of adaptation `a`; returns the SRER (host float)."""

@@ -186,6 +186,8 @@ def _ls_explicit(s, am, fm, f0range, window, fs):
     out_a = torch.zeros(2 * Kc, dtype=torch.float64, device=dev)
     out_b = torch.zeros(2 * Kc, dtype=torch.float64, device=dev)
     c.ls_explicit(up(s), N, up(am), up(fm), up(f0range), Kc, up(window), fs, out_a, out_b)
+    if c.ls_faults():                   # functions.py:465 / :530: inv() of a singular normal matrix
+        raise np.linalg.LinAlgError("Singular matrix")
     a = out_a.cpu().numpy().view(np.complex128).reshape(Kc, 1)
     b = out_b.cpu().numpy().view(np.complex128).reshape(Kc, 1)
     return a, b

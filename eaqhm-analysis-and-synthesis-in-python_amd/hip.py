@@ -22,6 +22,7 @@ SYMBOLS = (
     ("eaqhm_set_option", C.c_int, [_P, _I32, _I32]),
     ("eaqhm_debug_read", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("eaqhm_device_info", C.c_int, [_P, C.POINTER(_I32)]),
+    ("eaqhm_ls_faults", C.c_int, [_P, C.POINTER(_I32)]),
     ("eaqhm_frame_prep", C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
     ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _I32, _I32, _I32, _F64, _F64, _P, _P, _P]),
@@ -126,6 +127,12 @@ class Context:
         out = (C.c_uint64 * 16)()
         self._ck(self.lib.eaqhm_debug_read(self.h, out))
         return [int(v) for v in out]
+
+    def ls_faults(self):
+        """LS systems with a collapsed Cholesky pivot since the last read (waits for the stream, clears the count)."""
+        n = _I32(0)
+        self._ck(self.lib.eaqhm_ls_faults(self.h, C.byref(n)))
+        return int(n.value)
 
     def sync(self):
         self._ck(self.lib.eaqhm_sync(self.h))

@@ -50,15 +50,22 @@ int eaqhm_set_stream(eaqhm_ctx* ctx, void* hip_stream);
 int eaqhm_sync(eaqhm_ctx* ctx);
 const char* eaqhm_last_error(eaqhm_ctx* ctx);
 /* tuning knobs (for A/B measurements; defaults are the fastest validated choice)
- *   EAQHM_OPT_LS_VARIANT: 1 = VALU Gramian + column Cholesky through scratch (any size), 2 = MFMA Gramian + tile Cholesky through memory,
- *                         3 = Gramian and tile Cholesky on chip for frames of <= 6 column blocks, 2 for the rest
- *                             (default) */
+ *   EAQHM_OPT_LS_VARIANT: 2 = MFMA Gramian + tile Cholesky through memory for every frame (the large-frame kernel),
+ *                         3 = Gramian and tile Cholesky on chip for frames of <= 13 tile rows (Kc <= 103), the
+ *                             large-frame kernel for the rest (default) */
 #define EAQHM_OPT_LS_VARIANT 1
 #define EAQHM_OPT_DEBUG_KEEP 2   /* 1: accumulate the in-kernel phase stamps across launches */
 int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value);
 /* diagnostics: shader-clock cycles per phase of the LS tile kernel summed over frames (thread 0 of each
  * workgroup): {setup, basis build, contraction, factorisation total..., see csrc/eaqhm_ls_tile.hip STAMP} */
 int eaqhm_debug_read(eaqhm_ctx* ctx, uint64_t h_out[16]);
+/* singular systems: the reference aborts with numpy.linalg.LinAlgError from inv() when a frame's normal matrix is
+ * singular (functions.py:465, :530).  The kernels factorise by Cholesky; a pivot that collapses to <= 1e-12 of its
+ * diagonal entry (two identical basis columns, a slot whose track duplicates another) is counted, per frame, in a
+ * device counter instead of being passed on as a finite but meaningless solution.  eaqhm_ls_faults waits for the
+ * stream, returns the count since the last read and clears it; eaqhm_eval_synth also reports (and clears) it in
+ * sums_out[4], so the adaptation loop needs no extra device->host read.  The host raises LinAlgError. */
+int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t* h_count);
 /* library / device facts: fills {n_cu, lds_bytes, clock_khz, abi_version} */
 int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
 
@@ -139,8 +146,9 @@ int eaqhm_spline_solve_range(eaqhm_ctx* ctx, const double* records, int32_t No_t
  *   ph_knot          double[No_ti][Kmax] dense phase at the instants (what functions.py:411 packs)
  *   s_hat            double[L]
  *   partials         double[2*n_blocks] scratch for the deterministic two-level reduction
- *   sums_out         double[4]: {sum d, sum d^2, n, SRER dB} with d = target - s_hat over [s_lo,s_hi);
- *                    SRER uses std_det (functions.py:161) and is only meaningful for a full range.   */
+ *   sums_out         double[8]: {sum d, sum d^2, n, SRER dB, LS faults since the last read (see eaqhm_ls_faults), -, -, -}
+ *                    with d = target - s_hat over [s_lo,s_hi); SRER uses std_det (functions.py:161) and is only
+ *                    meaningful for a full range.                                                    */
 int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uint8_t* code, const double* mom,
                      int32_t No_ti, int32_t Kmax, int32_t step, double fs, int64_t L, int64_t t_lo, int64_t t_hi,
                      int64_t s_lo, int64_t s_hi, const double* target, double std_det, double* am_out,

@@ -20,6 +20,10 @@ Usage:
     python tests/golden/make_golden.py synth48k        # 0.6 s synthetic @48 kHz, maxAdpt=1
     python tests/golden/make_golden.py prep            # pre-processing-only fixtures
     python tests/golden/make_golden.py units           # small unit known-answers
+    python tests/golden/make_golden.py seed16k         # 1.2 s synthetic @16 kHz with a span of digital zeros:
+                                                       # provokes the empty-row seeding branch (functions.py:204-242)
+    python tests/golden/make_golden.py synth48k_p80    # 0.6 s synthetic @48 kHz, partials=80, maxAdpt=2
+    python tests/golden/make_golden.py prep48k60       # pre-processing of the 60 s @48 kHz bench workload
 """
 import os
 import sys
@@ -52,7 +56,8 @@ synth_speech_int16 = _synth.synth_speech_int16
 # --------------------------------------------------------------------------- capture machinery
 class Capture:
     def __init__(self, ls_frames_iqhm=(), ls_frames_eaqhm=(), dense_adpts=(0,), dense_k=(0, 30, 45),
-                 dense_ranges=((0, 9000), (30000, 36000)), rec_adpts=(0, 1)):
+                 dense_ranges=((0, 9000), (30000, 36000)), rec_adpts=(0, 1), ls_outputs_only=False,
+                 seeded_ls=0):
         self.out = {}
         self.ls_frames_iqhm = set(ls_frames_iqhm)
         self.ls_frames_eaqhm = set(ls_frames_eaqhm)
@@ -60,6 +65,9 @@ class Capture:
         self.dense_k = dense_k
         self.dense_ranges = dense_ranges
         self.rec_adpts = set(rec_adpts)
+        self.ls_outputs_only = ls_outputs_only   # large frames: keep (amp, slope) of the captured frames, not their inputs
+        self.seeded_ls = seeded_ls               # capture the LS in/out of this many seeded frames per adaptation
+        self.seeded = {}                         # adaptation -> [tith of the frames that took functions.py:204-242]
         self.n_iqhm = 0
         self.n_eaqhm = 0
         self.n_std = 0
@@ -123,10 +131,11 @@ class Capture:
         self.ti_a0.append(int(loc["tith"]))
         if idx in self.ls_frames_iqhm:
             p = "iqhm%d_" % idx
-            self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
-            self.out[p + "f0range"] = np.array(f0range, dtype=np.float64)
-            self.out[p + "window"] = np.array(window, dtype=np.float64)
-            self.out[p + "fs"] = np.int64(fs)
+            if not self.ls_outputs_only:
+                self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
+                self.out[p + "f0range"] = np.array(f0range, dtype=np.float64)
+                self.out[p + "window"] = np.array(window, dtype=np.float64)
+                self.out[p + "fs"] = np.int64(fs)
             self.out[p + "amp"] = np.array(amp).ravel()
             self.out[p + "slope"] = np.array(slo).ravel()
             self.out[p + "tith"] = np.int64(loc["tith"])
@@ -140,13 +149,22 @@ class Capture:
         loc = sys._getframe(1).f_locals
         a = int(loc["a"])
         self.stale_f0.setdefault(a, float(loc["f0"]))
-        if idx in self.ls_frames_eaqhm:
+        c = int(loc["tith"]) - 1
+        # the seeding branch (functions.py:204-213) leaves exactly these two literals at the frame centre
+        was_seeded = fm.shape[1] == 3 and loc["fm_current"][c, 0] == 140 and loc["am_current"][c, 0] == 10e-4
+        take = idx in self.ls_frames_eaqhm
+        if was_seeded:
+            lst = self.seeded.setdefault(a, [])
+            lst.append(int(loc["tith"]))
+            take = take or len(lst) <= self.seeded_ls
+        if take:
             p = "eaqhm%d_" % idx
-            self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
-            self.out[p + "am"] = np.array(am, dtype=np.float64)
-            self.out[p + "fm"] = np.array(fm, dtype=np.float64)
-            self.out[p + "window"] = np.array(window, dtype=np.float64)
-            self.out[p + "fs"] = np.int64(fs)
+            if not self.ls_outputs_only:
+                self.out[p + "s"] = np.array(s, dtype=np.float64).ravel()
+                self.out[p + "am"] = np.array(am, dtype=np.float64)
+                self.out[p + "fm"] = np.array(fm, dtype=np.float64)
+                self.out[p + "window"] = np.array(window, dtype=np.float64)
+                self.out[p + "fs"] = np.int64(fs)
             self.out[p + "amp"] = np.array(amp).ravel()
             self.out[p + "slope"] = np.array(slo).ravel()
             self.out[p + "tith"] = np.int64(loc["tith"])
@@ -262,6 +280,8 @@ def run_reference(wav, gender, cap, **kw):
     o["f0_a0"] = np.array(cap.f0_a0)
     o["ti_a0"] = np.array(cap.ti_a0, dtype=np.int64)
     o["stale_f0"] = np.array([[a, f] for a, f in sorted(cap.stale_f0.items())], dtype=np.float64).reshape(-1, 2)
+    for a, lst in cap.seeded.items():
+        o["seeded_tith_a%d" % a] = np.array(lst, dtype=np.int64)
     pack_det(det, "det_", o)
     return o
 
@@ -322,6 +342,49 @@ def job_synth48k():
         o.pop(k, None)
     os.unlink(wav)
     save("synth48k_0p6s_adpt1.npz", o)
+
+
+SEED16K_ZERO = (8000, 10800)     # digital silence: 175 ms inside the analysed region
+
+
+def job_seed16k():
+    """Empty-row seeding (functions.py:204-242, :286-292) and its aliasing into the kept result when the loop breaks
+    (:383, :397-402): frames whose window lies inside a span of digital zeros get no harmonic in adaptation 0, so
+    their fm_current row is empty in every later adaptation."""
+    fs = 16000
+    x = synth_speech_int16(1.2, fs).copy()
+    x[SEED16K_ZERO[0]:SEED16K_ZERO[1]] = 0
+    wav = write_wav_int16(x, fs)
+    cap = Capture(dense_adpts=(), rec_adpts=(1, 2), seeded_ls=2)
+    o = run_reference(wav, "female", cap, maxAdpt=6)
+    o["wav_int16"] = x
+    o["zero_span"] = np.array(SEED16K_ZERO, dtype=np.int64)
+    os.unlink(wav)
+    save("seed16k_1p2s_adpt6.npz", o)
+
+
+def job_synth48k_p80():
+    """48 kHz with partials=80 (all partials < 21.6 kHz: no near-Nyquist unwrap flips), so adaptations
+    >= 1 are well behaved and pin mode 1 of the large-frame LS kernel (Kc = 161, N up to 901)."""
+    fs = 48000
+    x = synth_speech_int16(0.6, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(ls_frames_iqhm=(100, 900), ls_frames_eaqhm=(100, 900, 1500), dense_adpts=(), rec_adpts=(1,),
+                  ls_outputs_only=True)
+    o = run_reference(wav, "female", cap, maxAdpt=2, partials=80)
+    o["wav_int16"] = x
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    os.unlink(wav)
+    save("synth48k_0p6s_p80_adpt2.npz", o)
+
+
+def job_prep48k60():
+    xs = synth_speech_int16(60.0, 48000)
+    r = prep_only(xs, 48000, "female")
+    o = {"synth48k_60s_" + k: v for k, v in r.items()}
+    o["synth48k_60s_f0s_5ms"] = np.ascontiguousarray(o["synth48k_60s_f0s_5ms"][:, :2])
+    save("prep_synth48k_60s.npz", o)
 
 
 def prep_only(x_int16, fs, gender):
@@ -403,6 +466,7 @@ def job_units():
 
 if __name__ == "__main__":
     jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
-                prep=job_prep, units=job_units)
+                prep=job_prep, units=job_units, seed16k=job_seed16k, synth48k_p80=job_synth48k_p80,
+                prep48k60=job_prep48k60)
     for j in sys.argv[1:]:
         jobs[j]()

@@ -270,9 +270,28 @@ def test_against_oracle_seeded_signal(amd, params):
     ti5 = np.array([f.ti for f in frames])
     sp = np.array([float(f.isSpeech) for f in frames])
     vo = np.array([float(f.isVoiced) for f in frames])
-    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=f0min, maxAdpt=2, step=params["step"],
-                    pitchPeriods=params["pitchPeriods"], analysisWindow=params["analysisWindow"],
-                    partials=params["partials"])
+    # rounding sensitivity of the frames themselves: the same NumPy normal equations solved with inv() (the reference,
+    # functions.py:465/:530) and by Cholesky (what the kernels do); see tools/conditioning_study.py
+    import scipy.linalg as sla
+    sens, plain_ls = [0.0, 0.0], O._weighted_ls
+
+    def two_roundings(E0, n, sw, window):
+        w = np.asarray(window, dtype=np.float64)[:, None]
+        Ew = w * np.concatenate((E0, n * E0), axis=1)
+        R, rhs = Ew.conj().T @ Ew, Ew.conj().T @ (w[:, 0] * sw)
+        x = np.linalg.inv(R) @ rhs
+        Kc = E0.shape[1]
+        sens[0] = max(sens[0], np.abs(x[:Kc] - sla.cho_solve(sla.cho_factor(R, lower=True), rhs)[:Kc]).max())
+        sens[1] = max(sens[1], np.abs(x[:Kc]).max())
+        return x[:Kc], x[Kc:]
+
+    O._weighted_ls = two_roundings
+    try:
+        ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=f0min, maxAdpt=2, step=params["step"],
+                        pitchPeriods=params["pitchPeriods"], analysisWindow=params["analysisWindow"],
+                        partials=params["partials"])
+    finally:
+        O._weighted_ls = plain_ls
     prologue.apply_full_waveform(frames, len(s), params["analysisWindow"] * params["step"])
     plan = FramePlan(len(s), fs, grid, frames, fstep, params["step"], params["pitchPeriods"],
                      params["analysisWindow"], params["partials"])
@@ -283,12 +302,17 @@ def test_against_oracle_seeded_signal(amd, params):
         nt = (2 * (2 * plan.frame_K + 1) + 1 + 15) // 16
         assert (nt <= 13).any() and (nt > 13).any()      # both LS kernels take part
     assert np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
-    # the mis-scaled pitch puts every other basis column between true partials: a less well conditioned fit
-    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= (1e-9 if f0scale == 1.0 else 5e-8)
+    # Conditioning-aware bar.  SURVEY §8c states its FP64 tolerances for cond(R) <= 1.1e5 (Q4); with the mis-scaled
+    # pitch every other basis column sits between true partials and cond(R) of adaptation 1 reaches 1.3e10
+    # (profiles/r02_parity/conditioning_f0scale.txt): inv() and Cholesky of the SAME NumPy matrices already differ by
+    # 3e-8 of the largest amplitude.  The kernels may be off by at most 3x that distance between two CPU roundings.
+    rel_sens = sens[0] / sens[1]
+    loose = max(1.0, 3.0 * rel_sens / TOL_AM_REL)
+    assert loose == 1.0 if f0scale == 1.0 else 1.0 < loose < 30.0, (rel_sens, loose)
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9 * loose
     m = ref["am"] != 0
     assert np.mean((fin["am"] != 0) == m) >= 0.999
     both = m & (fin["am"] != 0)
-    loose = 1.0 if f0scale == 1.0 else 10.0   # observed there: amplitudes 1.6e-8 of the maximum
     assert np.abs(fin["am"][both] - ref["am"][both]).max() <= loose * TOL_AM_REL * ref["am"].max()
     assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= loose * TOL_FM_HZ
     assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= loose * TOL_PH_RAD
@@ -406,3 +430,229 @@ def test_48khz_large_frames():
     strong = both & (ref["am"] > 1e-6 * ref["am"].max())      # the angle of a vanishing partial is ill-conditioned
     assert np.abs(wrap(ph[strong] - ref["ph"][strong])).max() <= TOL_PH_RAD
     assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------- hot-kernel raw LS solutions
+def _plan_for(s, fs, track, partials=0):
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import FramePlan
+    grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    return FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, partials)
+
+
+def _raw_of(eng, f):
+    """(amplitudes, slopes) of frame f as eaqhm_ls_batch left them in raw_amp / raw_slope (column order
+    [negative | DC | positive], the order iqhmLS_complexamps / eaqhmLS_complexamps return)."""
+    amp = eng.raw[0][f].cpu().numpy().view(np.complex128)
+    slo = eng.raw[1][f].cpu().numpy().view(np.complex128)
+    return amp, slo
+
+
+@pytest.mark.parametrize("variant", [3, 2])
+def test_batched_kernels_raw_solutions_sa19(amd, sa19_golden, variant):
+    """The BATCHED LS kernels (eaqhm_ls_tile_kernel for variant 3, eaqhm_ls_mfma_kernel for variant 2 — not the
+    one-frame seam kernel) against the reference's per-frame LS outputs: complex amplitudes AND slopes of all Kc
+    columns, negative-frequency block included, for four frames of adaptation 0 and four of adaptation 1."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis
+    g = sa19_golden
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    plan = _plan_for(s, fs, g["swipe_track"])
+    eng = DeviceAnalysis(s, s, plan, 160, 1, keep_raw=True)
+    eng.ctx.set_option(1, variant)
+    worst = {}
+
+    def hook(a, e):
+        for idx in (0, 700, 2000, 3500):
+            p = ("iqhm%d_" if a == 0 else "eaqhm%d_") % idx
+            assert int(g[p + "tith"]) - 1 == int(plan.frame_c[idx])
+            amp, slo = _raw_of(e, idx)
+            Kc = len(g[p + "amp"])
+            worst[(a, idx)] = (relerr(amp[:Kc], g[p + "amp"]), relerr(slo[:Kc], g[p + "slope"]))
+
+    eng.run(on_adaptation=hook)
+    assert len(worst) == 8
+    for (a, idx), (ea, es) in worst.items():
+        assert ea < 1e-9 and es < 1e-8, (a, idx, ea, es)
+
+
+def test_batched_kernel_raw_solutions_48khz(amd):
+    """Large frames (N up to 901, Kc 161-297: eaqhm_ls_mfma_kernel): raw LS solutions of adaptation 0 against the
+    reference on the full-band 48 kHz fixture (frame 100) and, with partials=80, of adaptations 0 AND 1 (mode 1 of
+    the large-frame kernel at Kc = 161); then the frame-centre records of adaptation 1 and the SRER list, which
+    the reference ends after adaptation 1 (39.81 -> 39.72 dB)."""
+    from eaqhm_amd.engine import DeviceAnalysis
+    fs = 48000
+    g = load_golden("synth48k_0p6s_adpt1.npz")
+    s = g["wav_int16"] / 32768.0
+    plan = _plan_for(s, fs, g["swipe_track"])
+    eng = DeviceAnalysis(s, s, plan, 160, 0, keep_raw=True)
+    eng.run()
+    amp, slo = _raw_of(eng, 100)
+    Kc = len(g["iqhm100_amp"])
+    assert relerr(amp[:Kc], g["iqhm100_amp"]) < 1e-9 and relerr(slo[:Kc], g["iqhm100_slope"]) < 1e-8
+
+    g = load_golden("synth48k_0p6s_p80_adpt2.npz")
+    s = g["wav_int16"] / 32768.0
+    plan = _plan_for(s, fs, g["swipe_track"], partials=80)
+    assert plan.Kmax == 80 and np.array_equal(2 * plan.frame_K + 1, g["ls_shapes_iqhm"][:, 1])
+    n0 = plan.n_frames
+    eng = DeviceAnalysis(s, s, plan, 160, 2, keep_raw=True)
+    seen = {}
+
+    def hook(a, e):
+        for idx in ((100, 900) if a == 0 else (100, 900, 1500)):
+            key = "iqhm%d_" % idx if a == 0 else "eaqhm%d_" % idx
+            if a > 0:
+                assert int(g[key + "a"]) == 1 and idx < n0
+            assert int(g[key + "tith"]) - 1 == int(plan.frame_c[idx])
+            amp, slo = _raw_of(e, idx)
+            Kc = len(g[key + "amp"])
+            assert relerr(amp[:Kc], g[key + "amp"]) < 1e-9, (a, idx)
+            assert relerr(slo[:Kc], g[key + "slope"]) < 1e-8, (a, idx)
+        seen[a] = e.records[0][:plan.No_ti].cpu().numpy().copy()
+
+    eng.run(on_adaptation=hook)
+    assert len(eng.SRER) == 2 and np.abs(np.array(eng.SRER) - g["SRER"]).max() < TOL_SRER_DB
+    ref = unpack_records(g, 1)
+    K = plan.Kmax
+    am, fm, ph = seen[1][:, :K], seen[1][:, K:2 * K], seen[1][:, 2 * K:3 * K]
+    assert np.mean((am != 0) == ref["mask"]) >= 0.999
+    both = (am != 0) & ref["mask"]
+    assert np.abs(am[both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(fm[both] - ref["fm"][both]).max() <= TOL_FM_HZ
+    strong = both & (ref["am"] > 1e-6 * ref["am"].max())
+    assert np.abs(wrap(ph[strong] - ref["ph"][strong])).max() <= TOL_PH_RAD
+    assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9
+
+
+# ----------------------------------------------------------------------------- empty-row seeding (Q7 / Q8)
+def check_seeding_result(g, srer, seen, fin, raw510=None):
+    """Shared by the single-GPU and the two-rank test: everything the reference's run on the signal with the span of
+    digital zeros pins (tests/golden/make_golden.py seed16k)."""
+    assert len(srer) == 4 and np.abs(np.array(srer) - g["SRER"]).max() < TOL_SRER_DB
+    assert np.abs(fin["s_recon"] - g["s_recon"]).max() <= 1e-9
+    K = fin["am"].shape[1]
+    for a in (1, 2):
+        ref = unpack_records(g, a)
+        am, fm, ph = seen[a][:, :K], seen[a][:, K:2 * K], seen[a][:, 2 * K:3 * K]
+        assert np.mean((am != 0) == ref["mask"]) >= 0.999
+        both = (am != 0) & ref["mask"]
+        assert np.abs(am[both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+        assert np.abs(fm[both] - ref["fm"][both]).max() <= TOL_FM_HZ
+        assert np.abs(wrap(ph[both] - ref["ph"][both])).max() <= TOL_PH_RAD
+        assert np.abs(seen[a][:, 3 * K] - ref["a0"]).max() <= TOL_AM_REL
+        # the seeded instants carry nothing (their frames see a silent signal)
+        inst = (g["seeded_tith_a%d" % a] - 1) // 15
+        assert len(inst) == 170 and np.all(am[inst] == 0)
+    for a in range(4):
+        gs = g["recsum%d" % a]
+        assert abs(np.count_nonzero(seen[a][:, :K]) - int(gs[0])) <= 2
+        assert abs(seen[a][:, :K].sum() - gs[1]) <= 1e-7 * abs(gs[1])
+    # Q8: the rejected adaptation 3 seeded its rows inside the arrays the kept result aliases
+    cells, ref_am = g["det_cells"], g["det_am"]
+    i, k = cells[:, 0], cells[:, 1]
+    ref_mask = np.zeros_like(fin["am"], dtype=bool)
+    ref_mask[i, k] = True
+    assert np.mean((fin["am"] != 0) == ref_mask) >= 0.999
+    q8 = ref_am == 10e-4
+    assert q8.sum() == 170
+    assert np.all(fin["am"][i[q8], 0] == 10e-4) and np.all(fin["fm"][i[q8], 0] == 0) and np.all(fin["pk"][i[q8], 0] == 0)
+    assert np.array_equal(np.flatnonzero(fin["am"][:, 0] == 10e-4), i[q8])
+    ok = fin["am"][i, k] != 0
+    assert np.abs(fin["am"][i, k][ok] - ref_am[ok]).max() <= TOL_AM_REL * ref_am.max()
+    assert np.abs(fin["fm"][i, k][ok] - g["det_fm"][ok]).max() <= TOL_FM_HZ
+    assert np.abs(wrap(fin["pk"][i, k][ok] - g["det_pk"][ok])).max() <= TOL_PH_RAD
+    if raw510 is not None:      # LS of the first seeded frame of adaptation 1: K = 1, columns [-140 Hz | DC | +140 Hz]
+        scale = max(np.abs(g["eaqhm510_amp"]).max(), 1e-300)
+        assert np.abs(raw510[0][:3] - g["eaqhm510_amp"]).max() <= 1e-9 * scale + 1e-18
+
+
+@pytest.mark.parametrize("variant", [3, 2])
+def test_empty_row_seeding_against_reference(amd, variant):
+    """functions.py:204-242, :286-292 and the aliasing on break :383, :397-402 (Q8): 175 ms of digital
+    zeros inside the analysed region; 170 frames per adaptation take the seeding branch from adaptation 1 on and the
+    stop rule fires at adaptation 3.  Both batched LS kernels."""
+    from eaqhm_amd import functions as F
+    from eaqhm_amd.engine import DeviceAnalysis
+    g = load_golden("seed16k_1p2s_adpt6.npz")
+    s = g["wav_int16"] / 32768.0
+    plan = _plan_for(s, 16000, g["swipe_track"])
+    assert np.array_equal(plan.ti[plan.analysed], g["ti_a0"])
+    eng = DeviceAnalysis(s, s, plan, 160, 6, keep_raw=True)
+    eng.ctx.set_option(1, variant)
+    seen, raw = {}, {}
+
+    def hook(a, e):
+        seen[a] = e.records[0][:plan.No_ti].cpu().numpy().copy()
+        if a == 1:
+            assert int(g["eaqhm510_tith"]) - 1 == int(plan.frame_c[510])
+            raw[510] = _raw_of(e, 510)
+            seeded = np.flatnonzero(e.seeded.cpu().numpy()) + 1
+            assert np.array_equal(seeded, g["seeded_tith_a1"])
+
+    eng.run(on_adaptation=hook)
+    fin = eng.final_arrays()
+    check_seeding_result(g, eng.SRER, seen, fin, raw[510])
+    det = F.pack_results(plan, fin)
+    d = det[int(g["det_cells"][g["det_am"] == 10e-4][0, 0])]
+    assert len(d.amplitudes) == 1 and d.amplitudes[0][0] == 10e-4 and d.frange[0][0] == 0
+    assert np.array_equal([len(x.amplitudes) if x.isVoiced else 0 for x in det], g["det_len"])
+
+
+# ----------------------------------------------------------------------------- singular systems, CLI
+def test_singular_system_raises_linalgerror(amd):
+    """The reference aborts with numpy.linalg.LinAlgError from inv() on a singular normal matrix
+    (functions.py:465, :530).  Two identical frequency columns: the seams raise instead of returning a silently
+    wrong solution; a healthy system still goes through."""
+    rng = np.random.default_rng(1)
+    N = 241
+    s = rng.standard_normal(N) * 0.1
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.iqhmLS_complexamps(s, np.array([-200.0, 0.0, 200.0, 200.0]), np.blackman(N), 16000)
+    fm = np.tile(np.array([-200.0, 0.0, 200.0, 200.0]), (N, 1))
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.eaqhmLS_complexamps(s, np.ones((N, 4)), fm, np.hamming(N), 16000)
+    a, b = amd.iqhmLS_complexamps(s, np.array([-200.0, 0.0, 200.0]), np.blackman(N), 16000)
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+
+
+def test_singular_frame_in_batch_raises(amd, sa19_golden):
+    """Two slots with identical tracks make two columns of every adaptation >= 1 frame identical: the batched kernel
+    counts the collapsed pivots (eaqhm_ls_faults) and the engine raises LinAlgError at the end of that adaptation
+    (the reference would abort inside the first such frame's inv())."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    s = s[:16000]
+    plan = _plan_for(s, fs, sa19_golden["swipe_track"][:1000])
+    eng = DeviceAnalysis(s, s, plan, 160, 2)
+    it = eng.adaptations()
+    next(it)                                    # adaptation 0 enqueued
+    next(it)                                    # its SRER read (healthy), adaptation 1 enqueued
+    eng.torch.cuda.synchronize()
+    eng.fm_cur[1].copy_(eng.fm_cur[0])          # slot 1 := slot 0 for the next adaptation's windows
+    eng.am_cur[1].copy_(eng.am_cur[0])
+    with pytest.raises(np.linalg.LinAlgError):
+        for _ in it:
+            pass
+
+
+def test_cli_writes_reconstruction(amd, tmp_path, sa19_golden, capsys):
+    """Headless counterpart of main.py:44-72: prints the SRER lines, writes <name>_reconstructed.wav as float32."""
+    import shutil
+    from scipy.io import wavfile
+    from eaqhm_amd import cli
+    wav = str(tmp_path / "SA19.WAV")
+    shutil.copy(os.path.join(GOLDEN, "SA19.WAV"), wav)
+    assert cli.main([wav, "--gender", "female", "--max-adpt", "1"]) == 0
+    out = capsys.readouterr().out
+    assert "SRER: " in out and "Adaptation No: 1" in out and "Signal adapted to" in out
+    fs, x = wavfile.read(str(tmp_path / "SA19_reconstructed.wav"))
+    assert fs == 16000 and x.dtype == np.float32 and x.shape == (63488,)
+    ref = sa19_golden["SRER"][1]
+    fs0, s0 = wavfile.read(wav)
+    s0 = s0 / 32768.0
+    assert abs(20 * np.log10(np.std(s0) / np.std(s0 - x)) - ref) < 1e-3      # float32 file, SWIPE' run by the CLI

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, workload="sa19"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -33,17 +33,31 @@ def _worker(rank, world, port, out_path):
             dist.all_reduce(host, group=self.group)
             t.copy_(host)
 
-    g = load_golden("sa19_female_default.npz")
-    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    if workload == "sa19":
+        g = load_golden("sa19_female_default.npz")
+        fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+        max_adpt = 5
+    else:           # the signal with a span of digital zeros (empty-row seeding), cut by the rank boundary
+        g = load_golden("seed16k_1p2s_adpt6.npz")
+        fs, s = 16000, g["wav_int16"] / 32768.0
+        max_adpt = 6
     grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     prologue.apply_full_waveform(frames, len(s), 480)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
-    eng = DeviceAnalysis(s, s, plan, 160, 5, shard=HostStaged(rank, world, dist.group.WORLD))
-    eng.run()
+    eng = DeviceAnalysis(s, s, plan, 160, max_adpt, shard=HostStaged(rank, world, dist.group.WORLD))
+    seen = {}
+
+    def hook(a, e):
+        rec = e.records[0].clone()
+        e.shard.all_gather_rows(rec, plan.No_ti)        # test-only: complete rows of this adaptation
+        seen["rec%d" % a] = rec[:plan.No_ti].cpu().numpy()
+
+    eng.run(on_adaptation=hook if workload != "sa19" else None)
     fin = eng.final_arrays()
     if rank == 0:
-        np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, **fin)
+        np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, bounds=np.array(eng.shard.bounds),
+                 **fin, **seen)
     dist.destroy_process_group()
 
 
@@ -64,3 +78,19 @@ def test_two_ranks_one_gpu_matches_reference(tmp_path, sa19_golden):
     assert np.abs(got["fm"][i, k][ok] - g["det_fm"][ok]).max() <= 1e-3
     d = (got["pk"][i, k][ok] - g["det_pk"][ok] + np.pi) % (2 * np.pi) - np.pi
     assert np.abs(d).max() <= 1e-5
+
+
+def test_two_ranks_seeding_across_the_rank_boundary(tmp_path):
+    """The silent span (instants 534-719) straddles the boundary between the two ranks' instant ranges: seeded rows of
+    rank 0 are visible inside rank 1's first windows only through the halo frames' flags (engine.py n_ext)."""
+    import torch.multiprocessing as mp
+    from test_gpu_parity import check_seeding_result
+    g = load_golden("seed16k_1p2s_adpt6.npz")
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(2, 29300 + os.getpid() % 300, out, "seed"), nprocs=2, join=True)
+    got = np.load(out)
+    b = got["bounds"]
+    z0, z1 = g["zero_span"] // 15
+    assert z0 + 20 < b[1] < z1 - 20, "rank boundary %d not inside the silent span %d..%d" % (b[1], z0, z1)
+    seen = {a: got["rec%d" % a] for a in range(4)}
+    check_seeding_result(g, got["SRER"], seen, {k: got[k] for k in ("am", "fm", "pk", "a0", "s_recon")})

@@ -109,8 +109,43 @@ def test_sharding_ranges():
             assert max(h - l for l, h in got) <= -(-T // world)
 
 
+def test_cost_balanced_sharding():
+    """ranges balanced by the sum of F(N, Kc), not by the number of instants."""
+    from eaqhm_amd.engine import Sharding, ls_cost
+    T = 4000
+    cost = np.where(np.arange(T) < 2000, ls_cost(241, 53), ls_cost(301, 97))     # high pitch, then low pitch: 4.6x
+    cost[:32] = 0
+    cost[-32:] = 0                                                               # instants that are not analysed
+    for world in (2, 4, 8):
+        b = Sharding(0, world).balance(T, cost)
+        assert b[0] == 0 and b[-1] == T and all(x <= y for x, y in zip(b, b[1:]))
+        shares = np.array([cost[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert shares.max() / shares.mean() < 1.01
+        counts = np.diff(b)
+        assert counts.max() / counts.min() > 2.0
+        assert [Sharding(r, world).balance(T, cost) for r in range(world)] == [b] * world    # same on every rank
+    assert Sharding(0, 4).balance(10, np.zeros(10)) == [0, 3, 6, 9, 10]          # nothing to balance: equal counts
+
+
+def test_cli_needs_the_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import eaqhm_amd
+    from eaqhm_amd import cli
+    with pytest.raises(eaqhm_amd.HipUnavailable):
+        cli.main([os.path.join(GOLDEN, "SA19.WAV"), "--gender", "female", "--max-adpt", "0", "--no-write"])
+
+
+def _pitch_profile(t, profile):
+    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    if profile == "step":      # a pitch track that drops to 0.7 of the true pitch half way: the second half's frames
+        f0 = np.where(t < 0.5 * t[-1], f0, 0.7 * f0)    # have ~1.4x the harmonics and longer windows (~3x the cost)
+    return f0
+
+
 # ----------------------------------------------------------------------------- world_size = 2 over gloo
-def _sharded_worker(rank, world, port, out_path):
+def _sharded_worker(rank, world, port, out_path, profile="true"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -126,43 +161,52 @@ def _sharded_worker(rank, world, port, out_path):
     fs = 16000
     s = synth_speech_int16(0.62, fs) / 32768.0
     t = np.arange(0, len(s) / fs, 0.001)
-    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    f0 = _pitch_profile(t, profile)
     grid = prologue.resample_track(np.column_stack([t, f0]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     prologue.apply_full_waveform(frames, len(s), 480)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
-    eng = DeviceAnalysis(s, s, plan, 160, 2, shard=Sharding(rank, world, dist.group.WORLD), ctx=OracleBackend())
+    eng = DeviceAnalysis(s, s, plan, 100, 2, shard=Sharding(rank, world, dist.group.WORLD), ctx=OracleBackend())
     eng.run()
     fin = eng.final_arrays()
     if rank == 0:
-        np.savez(out_path, SRER=np.array(eng.SRER), n_frames_rank0=eng.n_ls_frames, **fin)
+        np.savez(out_path, SRER=np.array(eng.SRER), n_frames_rank0=eng.n_ls_frames, bounds=np.array(eng.shard.bounds),
+                 **fin)
     dist.destroy_process_group()
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("world", [2, 4])
-def test_two_rank_gloo_matches_single_process(tmp_path, world):
-    """world 4 has interior ranks (two neighbours each) for the boundary-row exchange."""
+@pytest.mark.parametrize("world,profile", [(2, "true"), (4, "true"), (2, "step")])
+def test_two_rank_gloo_matches_single_process(tmp_path, world, profile):
+    """world 4 has interior ranks (two neighbours each) for the boundary-row exchange; the "step" pitch profile makes
+    the second half of the file ~3x as expensive per frame, so the cost-balanced ranges differ clearly in length."""
     import torch.multiprocessing as mp
     import eaqhm_oracle as O
     from eaqhm_amd import prologue
     from eaqhm_amd.synth import synth_speech_int16
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_sharded_worker, args=(world, 29000 + os.getpid() % 2000 + world, out), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, 29000 + os.getpid() % 2000 + world + 10 * len(profile), out, profile),
+             nprocs=world, join=True)
     got = np.load(out)
     fs = 16000
     s = synth_speech_int16(0.62, fs) / 32768.0
     t = np.arange(0, len(s) / fs, 0.001)
-    f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
+    f0 = _pitch_profile(t, profile)
+    b = got["bounds"]
+    if profile == "step":
+        assert (b[1] - b[0]) > 1.3 * (b[2] - b[1]), "ranges not cost-balanced: %r" % (b,)
     grid = prologue.resample_track(np.column_stack([t, f0]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     ref = O.analyse(s, fs, grid, np.array([f.ti for f in frames]), np.array([float(f.isSpeech) for f in frames]),
-                    np.array([float(f.isVoiced) for f in frames]), fstep, f0min=160, maxAdpt=2)
+                    np.array([float(f.isVoiced) for f in frames]), fstep, f0min=100, maxAdpt=2)
     assert len(got["SRER"]) == len(ref["SRER"])
     assert np.abs(got["SRER"] - np.array(ref["SRER"])).max() < 1e-9
-    assert np.abs(got["s_recon"] - ref["s_recon"]).max() < 1e-11
-    assert np.abs(got["am"] - ref["am"]).max() < 1e-12 and np.abs(got["fm"] - ref["fm"]).max() < 1e-7
-    assert np.abs(got["pk"] - ref["pk"]).max() < 1e-9 and np.abs(got["a0"] - ref["a0"]).max() < 1e-12
+    # (the same NumPy code on both sides; the mis-scaled pitch of "step" gives badly conditioned systems, where the
+    # ranks' 2 BLAS threads and this process's 8 already round differently: profiles/r02_parity/conditioning_f0scale.txt)
+    lo = 1.0 if profile == "true" else 1e3
+    assert np.abs(got["s_recon"] - ref["s_recon"]).max() < 1e-11 * lo
+    assert np.abs(got["am"] - ref["am"]).max() < 1e-12 * lo and np.abs(got["fm"] - ref["fm"]).max() < 1e-7 * lo
+    assert np.abs(got["pk"] - ref["pk"]).max() < 1e-9 * lo and np.abs(got["a0"] - ref["a0"]).max() < 1e-12 * lo
     assert 0 < int(got["n_frames_rank0"]) < ref["n_ls_frames"]      # rank 0 analysed only its share
 
 

@@ -84,6 +84,77 @@ def test_synth16k_run():
     assert np.abs(r["s_recon"] - g["s_recon"]).max() < 1e-11
 
 
+def test_seeding_run():
+    """Empty-row seeding (functions.py:204-242, :286-292) and its aliasing into the kept result when the
+    stop rule fires (:383, :397-402; Q8): 1.2 s of synthetic speech with 175 ms of digital zeros.  170 frames per
+    adaptation take the branch from adaptation 1 on; the loop breaks at adaptation 3 with the seeds of that
+    adaptation already written into the arrays the result of adaptation 2 aliases."""
+    g = load_golden("seed16k_1p2s_adpt6.npz")
+    s = g["wav_int16"] / 32768.0
+    assert np.all(s[g["zero_span"][0]:g["zero_span"][1]] == 0)
+    seen, seeded = {}, {}
+    an = O.Analysis(s, 16000, g["f0s_5ms"], g["vuv_ti"], g["vuv_isSpeech"], g["vuv_isVoiced"], int(g["frame_step"]),
+                    f0min=160, maxAdpt=6)
+    for a in range(7):
+        rec = an.ls_stage(a)
+        seeded[a] = np.array(an.seeded) + 1
+        seen[a] = rec
+        an.post_stage(a, rec)
+        if an.done:
+            break
+    r = an.result()
+    assert len(r["SRER"]) == 4 and np.abs(np.array(r["SRER"]) - g["SRER"]).max() < 1e-9
+    assert np.abs(r["s_recon"] - g["s_recon"]).max() < 1e-11
+    for a in (1, 2, 3):
+        assert np.array_equal(seeded[a], g["seeded_tith_a%d" % a]) and len(seeded[a]) == 170
+    for a in (1, 2):
+        gr = unpack_records(g, a)
+        assert np.array_equal(seen[a]["am"] != 0, gr["mask"])
+        assert np.abs(seen[a]["am"] - gr["am"]).max() <= 1e-11 * gr["am"].max()
+        assert np.abs(seen[a]["fm"] - gr["fm"]).max() <= 1e-4
+        assert np.abs(wrap(seen[a]["ph"] - gr["ph"])).max() <= 1e-7
+        assert np.abs(seen[a]["a0"] - gr["a0"]).max() <= 1e-12
+    for a in range(4):
+        gs = g["recsum%d" % a]
+        assert np.count_nonzero(seen[a]["am"]) == int(gs[0])
+        assert np.allclose([seen[a]["am"].sum(), seen[a]["fm"].sum()], gs[1:3], rtol=1e-9, atol=1e-9)
+    # the LS of seeded frames: K = 1, columns [-140 Hz | DC | +140 Hz] built from the seeded track
+    for idx in (510, 511, 1726, 2942):
+        p = "eaqhm%d_" % idx
+        a_, b_ = O.eaqhm_ls(g[p + "s"], g[p + "am"], g[p + "fm"], g[p + "window"], 16000)
+        assert np.array_equal(g[p + "slots"], [0, 1, 2])
+        assert np.abs(a_ - g[p + "amp"]).max() <= 1e-12 * max(np.abs(a_).max(), 1e-30)
+    # returned structs: the 10e-4 entries of slot 0 at the instants seeded during the rejected adaptation
+    cells, am = g["det_cells"], g["det_am"]
+    i, k = cells[:, 0], cells[:, 1]
+    assert np.count_nonzero(r["am"]) == len(cells)
+    assert np.abs(r["am"][i, k] - am).max() <= 1e-11
+    q8 = am == 10e-4
+    assert q8.sum() == 170 and np.all(k[q8] == 0)
+    assert np.array_equal(r["ti"][i[q8]] + 1, g["seeded_tith_a3"])
+    assert np.all(r["fm"][i[q8], 0] == 0) and np.all(g["det_fm"][q8] == 0)
+    assert np.abs(r["fm"][i, k] - g["det_fm"]).max() <= 1e-5
+    assert np.abs(wrap(r["pk"][i, k] - g["det_pk"])).max() <= 1e-7
+
+
+@pytest.mark.slow
+def test_synth48k_partials80():
+    """48 kHz with partials=80 (no near-Nyquist partials): adaptation 1 is well behaved, so the eaQHM LS at the
+    large-frame sizes (Kc = 161, N up to 901) is pinned; the reference stops after adaptation 1 (39.81 -> 39.72 dB)."""
+    g = load_golden("synth48k_0p6s_p80_adpt2.npz")
+    s = g["wav_int16"] / 32768.0
+    seen = {}
+    r = O.analyse(s, 48000, g["f0s_5ms"], g["vuv_ti"], g["vuv_isSpeech"], g["vuv_isVoiced"], int(g["frame_step"]),
+                  f0min=160, maxAdpt=2, partials=80, on_adaptation=lambda a, rec, st: seen.update({a: rec}))
+    assert len(r["SRER"]) == 2 and np.abs(np.array(r["SRER"]) - g["SRER"]).max() < 1e-8
+    gr = unpack_records(g, 1)
+    assert np.mean((seen[1]["am"] != 0) == gr["mask"]) >= 0.9999
+    both = (seen[1]["am"] != 0) & gr["mask"]
+    assert np.abs(seen[1]["am"][both] - gr["am"][both]).max() <= 1e-10 * gr["am"].max()
+    assert np.abs(seen[1]["fm"][both] - gr["fm"][both]).max() <= 1e-4
+    assert np.abs(r["s_recon"] - g["s_recon"]).max() < 1e-10
+
+
 @pytest.mark.slow
 def test_sa19_full_run(sa19_golden, sa19_signal):
     """BASELINE config 1/2: SA19.WAV, 'female', defaults; all six adaptations, every stage pinned."""
