@@ -214,7 +214,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   const size_t zloc_bytes = (((size_t)Kmax * L * sizeof(unsigned short)) + 255) & ~(size_t)255;
   const size_t ztot_bytes = (((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255;
   const size_t flag_bytes = zloc_bytes + ztot_bytes + (((size_t)zchunks + 255) & ~(size_t)255);
-  const size_t cls_bytes = ((16 + (size_t)6 * n_frames) * sizeof(int) + 255) & ~(size_t)255;
+  const size_t cls_bytes = ((16 + (size_t)LS_NCLS * n_frames) * sizeof(int) + 255) & ~(size_t)255;
   int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
   if (rc) return rc;
   B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes);

@@ -7,6 +7,9 @@
 
 namespace eaqhm {
 
+#define LS_NCLS 7
+#define LS_BIG_CLASS (LS_NCLS - 1)
+
 struct LsArgs {
   int mode;  // 0: adaptation 0 (stationary harmonics), 1: adaptation >= 1 (tracks)
   const double* s; long long L; double fs;
@@ -21,8 +24,8 @@ struct LsArgs {
   // fm_cur[k] from the start of t's 1024-sample chunk up to t, ztot[k][chunk] = zeros of the whole chunk
   const unsigned short* zloc; const int* ztot; int zchunks;
   unsigned char* zflag;   // [zchunks] chunks some frame window of this launch touches (only those are counted)
-  // frames bucketed by size (tile variant): cls[0..5] counts, cls[8..13] cursors, cls[16 + c*n_frames + i] frame ids.
-  // Classes 0-4 are the register budgets of eaqhm_ls_tile_kernel, class 5 is left to eaqhm_ls_mfma_kernel.
+  // frames bucketed by size (tile variant): cls[0..6] counts, cls[8..14] cursors, cls[16 + c*n_frames + i] frame ids.
+  // Classes 0-5 are the register budgets of eaqhm_ls_tile_kernel, class LS_BIG_CLASS is left to eaqhm_ls_mfma_kernel.
   int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
   int* fault;                 // device counter of singular systems (eaqhm_ctx::faults)

@@ -50,7 +50,7 @@ __device__ inline void tile_of(int q, int& I, int& J) {
 
 extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int TS, int ldx_max, int min_nb) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (min_nb > 0 && A.cls[5] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
+  if (min_nb > 0 && A.cls[LS_BIG_CLASS] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
   const int tid = threadIdx.x, nt = MF_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the unit bookkeeping in SGPRs
@@ -76,16 +76,16 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
   __syncthreads();
   const int PE = TS / 2;  // sample pairs per chunk
 
-  // after eaqhm_ls_tile_kernel (min_nb > 0) only the frames of size class 5 are left, usually none
-  const int n_items = (min_nb > 0) ? A.cls[5] : A.n_frames;
+  // after eaqhm_ls_tile_kernel (min_nb > 0) only the frames of the last size class are left, usually none
+  const int n_items = (min_nb > 0) ? A.cls[LS_BIG_CLASS] : A.n_frames;
   for (;;) {
-    if (tid == 0) shi[0] = atomicAdd((min_nb > 0) ? (A.cls + 8 + 5) : A.work_counter, 1);
+    if (tid == 0) shi[0] = atomicAdd((min_nb > 0) ? (A.cls + 8 + LS_BIG_CLASS) : A.work_counter, 1);
     __syncthreads();
     const int item = uni(shi[0]);
     __syncthreads();
     if (item >= n_items) break;
     // (wave-uniform, but out of LDS / memory: scalar registers for everything derived from them)
-    const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)5 * A.n_frames + item] : item);
+    const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)LS_BIG_CLASS * A.n_frames + item] : item);
     const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
     const int N = 2 * wl + 1, mid = wl;
     const int n = uni((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);

@@ -156,9 +156,103 @@ __device__ inline double scan16(double x) {
   return x;
 }
 
+// ---- adaptation 0: the Gramian in closed form ------------------------------------------------------------------
+// At adaptation 0 the basis columns are exp(j h theta n), h = -K..K, theta = 2 pi f0 / fs, on the symmetric grid
+// n = -wl..wl with a symmetric window (functions.py:444-455), so every entry of the three Gramian blocks depends on
+// the DIFFERENCE of the two harmonic numbers only (the blocks are Toeplitz):
+//     sum_n w^2 n^p exp(j m theta n)   =   c0[|m|]  (p = 0, real) | j sgn(m) s1[|m|]  (p = 1) | c2[|m|]  (p = 2, real),
+// 3 (2K+1) real sums of wl terms instead of a contraction over N x (2 Kc)^2, and the right-hand sides are K+1 complex
+// sums  r_p[h] = sum_n w^2 n^p s_n exp(j h theta n).  The tables are built here (pairs +-t share a rotation; within a
+// chunk of <= 64 samples exp(j m theta t) advances by complex rotation from an exactly evaluated seed), then every
+// wave fills its own system tiles from them: no basis image, no MFMA contraction for adaptation 0.
+#define TZ_TB 104     // table stride: m = 0 .. 2 n <= 102
+#define TZ_NCH 8      // chunks of the t range (deterministic two-level summation)
+#define TZ_NQ 7       // c0, s1, c2, Re r0, Im r0, Re r1, Im r1
+__device__ inline void toeplitz_tables(double* tab, double* part, double* W2, double* PA, double* PB, double* ssq,
+                                       const double* win, const double* sig, int n, int wl, double theta, int tid) {
+  const int mid = wl;
+  for (int t = tid; t <= wl; t += TL_THREADS) {
+    const double w = win[mid + t], w2 = w * w, sp = sig[mid + t], sm = sig[mid - t];
+    W2[t] = w2;
+    PA[t] = w2 * (sp + sm);
+    PB[t] = w2 * (sp - sm);
+  }
+  __syncthreads();
+  if (tid < 64) {   // signal energy sum w^2 s^2 (fixed summation order)
+    double e = 0.0;
+    for (int t = tid; t <= wl; t += 64) {
+      const double sp = sig[mid + t], sm = sig[mid - t];
+      e += W2[t] * ((t == 0) ? sp * sp : (sp * sp + sm * sm));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (tid == 0) ssq[0] = e;
+  }
+  const int nm = 2 * n + 1, CL = (wl + TZ_NCH - 1) / TZ_NCH;
+  for (int task = tid; task < nm * TZ_NCH; task += TL_THREADS) {
+    const int ch = task / nm, m = task - ch * nm;
+    const int t0 = 1 + ch * CL, t1 = (t0 + CL - 1 < wl) ? (t0 + CL - 1) : wl;
+    const double phi = (double)m * theta;
+    double zr, zi, sr, si;
+    sincos_cw((double)t0 * phi, &zi, &zr);
+    sincos_cw(phi, &si, &sr);
+    double a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    const bool rhs = m <= n;
+    for (int t = t0; t <= t1; ++t) {
+      const double w2 = W2[t], tt = (double)t, w2t = w2 * tt;
+      a0 = fma(w2, zr, a0);
+      a1 = fma(w2t, zi, a1);
+      a2 = fma(w2t * tt, zr, a2);
+      if (rhs) {
+        const double pa = PA[t], pb = PB[t];
+        b0 = fma(pa, zr, b0);
+        b1 = fma(pb, zi, b1);
+        b2 = fma(tt * pb, zr, b2);
+        b3 = fma(tt * pa, zi, b3);
+      }
+      const double nr = zr * sr - zi * si, ni = zr * si + zi * sr;
+      zr = nr; zi = ni;
+    }
+    double* pp = part + (size_t)(ch * TZ_NQ) * TZ_TB + m;
+    pp[0] = a0; pp[TZ_TB] = a1; pp[2 * TZ_TB] = a2;
+    pp[3 * TZ_TB] = b0; pp[4 * TZ_TB] = b1; pp[5 * TZ_TB] = b2; pp[6 * TZ_TB] = b3;
+  }
+  __syncthreads();
+  for (int q = tid; q < TZ_NQ * nm; q += TL_THREADS) {
+    const int k = q / nm, m = q - k * nm;
+    double v = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < TZ_NCH; ++ch) v += part[(size_t)(ch * TZ_NQ + k) * TZ_TB + m];
+    if (k < 3) v *= 2.0;                                   // the pair (+t, -t)
+    if (k == 0) v += W2[0];                                // t = 0
+    if (k == 3 && m <= n) v += W2[0] * sig[mid];
+    tab[k * TZ_TB + m] = v;
+  }
+  __syncthreads();
+}
+
+// entry (gi, gj) of the stacked system  Y^H Y,  Y = w [E | n E | s],  from the tables (adaptation 0)
+__device__ inline void toeplitz_entry(const double* tab, double ssq, int gi, int gj, int n, int Kc, double& re, double& im) {
+  re = 0.0; im = 0.0;
+  const int sigc = 2 * Kc;
+  if (gi > sigc || gj > sigc) return;                       // padding: set by the caller
+  auto harm = [&](int c) { const int cc = (c >= Kc) ? c - Kc : c; return (cc < n) ? -(cc + 1) : (cc - n); };
+  if (gi == sigc && gj == sigc) { re = ssq; return; }
+  if (gi == sigc || gj == sigc) {                           // right-hand-side row (or its mirror column)
+    const int c = (gi == sigc) ? gj : gi, b = (c >= Kc) ? 1 : 0, h = harm(c), ah = (h < 0) ? -h : h;
+    re = tab[(3 + 2 * b) * TZ_TB + ah];
+    im = tab[(4 + 2 * b) * TZ_TB + ah];
+    if ((h < 0) != (gj == sigc)) im = -im;                  // r[-h] = conj r[h]; the mirror column holds conj
+    return;
+  }
+  const int p = ((gi >= Kc) ? 1 : 0) + ((gj >= Kc) ? 1 : 0), m = harm(gj) - harm(gi), am = (m < 0) ? -m : m;
+  if (p == 1) im = (m < 0) ? -tab[TZ_TB + am] : tab[TZ_TB + am];
+  else re = tab[p * TZ_TB + am];
+}
+
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
 // the five budgets into one kernel body spills several hundred VGPRs).
-template <int NS>
+template <int NS, int MODE>
 __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, int ldx_max_, double* lds, int f_) {
   const int TS = uni(TS_), ldx_max = uni(ldx_max_), f = uni(f_);
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
@@ -191,8 +285,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   const int Npad = ((uni(A.Nmax) + 63) >> 6) << 6;
   double* Qs = uni(A.scratch) + (size_t)blockIdx.x * (size_t)uni((int)A.scratch_stride);  // bridged fm[j][t]
   double* Rs = Qs + (size_t)Npad * uni(A.nmax);                                           // bridged am[j][t]
-  const int mode = uni(A.mode);
-  const bool seeds = uni((int)((mode == 1) && A.any_seed && (*A.any_seed != 0))) != 0;
+  constexpr int mode = MODE;
+  const bool seeds = (mode == 1) && (uni((int)(A.any_seed && (*A.any_seed != 0))) != 0);
   // phases are q * (2 pi / fs) here, (2 pi q) / fs in the reference (functions.py:513, :453): one rounding each way,
   // <= 2 ulp of the phase apart, and no IEEE division per basis sample
   const double w1 = uni(2.0 * M_PI / A.fs);
@@ -225,7 +319,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
 
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
-    for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
+    if constexpr (MODE == 1)
+      for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
     for (int t = tid; t < N; t += nt_thr) {
       win[t] = window_value(mode == 0, t, N);
       sig[t] = sA[(size_t)(c - wl) + t];
@@ -254,8 +349,31 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     }
 
     // ================= Gramian =================
+    if constexpr (MODE == 0) {   // closed form (Toeplitz tables), see toeplitz_tables
+      double* tab = U;                                   // [TZ_NQ][TZ_TB]
+      double* part = tab + TZ_NQ * TZ_TB;                // [TZ_NCH][TZ_NQ][TZ_TB]
+      double* W2 = part + TZ_NCH * TZ_NQ * TZ_TB;        // [wl+1] each
+      double* PA = W2 + 64 * CI_NCH / 2 + 8;
+      double* PB = PA + 64 * CI_NCH / 2 + 8;
+      toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, n, wl, f0 * w1, tid);
+      const double ssq = sh[0];
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        if (!live[sl]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double re, im;
+          toeplitz_entry(tab, ssq, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, n, Kc, re, im);
+          accR[sl][r] = re;
+          accI[sl][r] = im;
+        }
+      }
+      __syncthreads();   // region U (tables) is reused as tile storage below
+      STAMP(2);
+    }
     // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid, taken from the centre outwards so that the phase
     // integral of functions.py:508-515 relative to the centre is a running sum
+    if constexpr (MODE == 1)
     for (int d0 = 0; d0 < npairs; d0 += PE) {
       // logical column cc of chunk rows (2*el, 2*el+1) lives at XCOL(cc, el): the 16 lanes that write one column
       // of 16 different pairs hit 16 different banks, and MFMA operand reads stay conflict-free
@@ -348,6 +466,21 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       STAMP(12);
       __syncthreads();
       STAMP(1);
+      // Touch the track lines the NEXT chunk's build will read (four runs of <= 136 bytes per slot: at most eight
+      // 128-byte lines), one load per thread, issued now and consumed after the contraction: the build then finds
+      // its six values per item in L1/L2 instead of waiting a DRAM round trip per chunk with the matrix pipe idle.
+      double pf = 0.0;
+      {
+        const int d1 = d0 + PE, jp = tid >> 3, q = tid & 7;
+        if (d1 <= mid && jp < n) {
+          const double* base = ((const double**)(ci + jp * CI_STRIDE))[2 + (q >> 2)];   // fm runs, then am runs
+          const int ext = 15 + (q >> 2);
+          int off = ((q & 3) == 0) ? (mid - d1 - ext) : ((q & 3) == 1) ? (mid - d1) : ((q & 3) == 2) ? (mid + d1) : (mid + d1 + ext);
+          off = (off < 0) ? 0 : (off > N - 1) ? (N - 1) : off;
+          pf = base[off];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;   // sample pairs in this chunk
       const int ksl = (pcs + 1) >> 1;                             // k-steps (4 rows each) that hold samples
 #pragma unroll
@@ -407,10 +540,11 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           aR = naR; aI = naI; bR = nbR; bI = nbI;
         }
       }
+      asm volatile("" ::"v"(pf));   // (the prefetched value itself is not used)
       __syncthreads();
       STAMP(2);
     }
-    if constexpr (M3) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
+    if constexpr (M3 && MODE == 1) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
         const d4 p1 = accR[sl], p2 = acc3[sl];
@@ -441,27 +575,54 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         for (int r = 0; r < 4; ++r)
           if (lq + 4 * r == lcol) dorig[16 * tP[sl] + lcol] = accR[sl][r];
       }
+      // Right-looking tile Cholesky with look-ahead.  Stage jb: the trailing update with panel jb-1 — the diagonal tile
+      // (jb, jb) first, whose owner then factorises and inverts it on its own (diag_wave: one wave, matrix cores, no
+      // workgroup barrier) while the other waves are still in their updates — barrier — panel jb — barrier.
+      double* dws = Dc;   // wave-private scratch of the diagonal step (only one wave is in it at a time)
+#define TRAILING_UPDATE(sl)                                                                         \
+  {                                                                                                 \
+    const double* ar = PanR + tP[sl] * TL_TILE;                                                     \
+    const double* ai = PanI + tP[sl] * TL_TILE;                                                     \
+    const double* br = PanR + tQ[sl] * TL_TILE;                                                     \
+    const double* bi = PanI + tQ[sl] * TL_TILE;                                                     \
+    /* T -= L_P L_Q^H, three real products: P1 = re re', P2 = im im', P3 = (re+im)(im'-re');   */   \
+    /* Re -= P1 + P2,  Im += P3 + P1 - P2  (P3 accumulates straight into the imaginary part)   */   \
+    d4 p1 = (d4){0, 0, 0, 0}, p2 = (d4){0, 0, 0, 0};                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                              \
+      const int o = (4 * ks + lq) * TL_LD + lcol;                                                   \
+      const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];                                  \
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lR, p1, 0, 0, 0);                               \
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, lI, p2, 0, 0, 0);                               \
+      accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, lI - lR, accI[sl], 0, 0, 0);         \
+    }                                                                                               \
+    accR[sl] = accR[sl] - (p1 + p2);                                                                \
+    accI[sl] = accI[sl] + (p1 - p2);                                                                \
+  }
       for (int jb = 0; jb < nt; ++jb) {
-        const int xd = jb * (jb + 1) / 2 + jb;
-        if (wave == (xd % TL_CW)) {  // publish the diagonal tile: Dc[row][col] = T[row][col]
-          const int sd = xd / TL_CW;
+        d4 Rt = (d4){0, 0, 0, 0}, It = (d4){0, 0, 0, 0};
+        bool mine = false;
 #pragma unroll
-          for (int sl = 0; sl < NS; ++sl)
-            if (sl == sd) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                Dc[2 * ((lq + 4 * r) * DG_LD + lcol)] = accR[sl][r];
-                Dc[2 * ((lq + 4 * r) * DG_LD + lcol) + 1] = accI[sl][r];
-              }
-            }
+        for (int sl = 0; sl < NS; ++sl) {
+          if (!live[sl] || tP[sl] != jb || tQ[sl] != jb) continue;
+          if (jb > 0) TRAILING_UPDATE(sl)
+          Rt = accR[sl]; It = accI[sl];
+          mine = true;
         }
-        diag_init(Zc, tid);
-        __syncthreads();  // (A) diagonal tile published, inverse initialised
-        STAMP(6);
         // real unknowns: every position but, in the last tile, the signal column `is` and the padding behind it
-        diag_coop(Dc, Zc, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, tid, dorig + 16 * jb,
-                  (jb == nt - 1) ? is : 16, uni(A.fault));  // ends with a barrier
+        if (mine)
+          diag_wave(Rt, It, dws, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, jb == nt - 1, dorig + 16 * jb,
+                    (jb == nt - 1) ? is : 16, uni(A.fault));
         STAMP(10);
+        if (jb > 0) {
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) {
+            if (!live[sl] || tQ[sl] < jb || (tP[sl] == jb && tQ[sl] == jb)) continue;
+            TRAILING_UPDATE(sl)
+          }
+        }
+        STAMP(8);
+        __syncthreads();  // (A) inverse of the diagonal tile published; every read of panel jb-1 done
+        STAMP(6);
         // ---- panel tiles (P > jb, Q == jb): X = T W^H, published as Pan[P][k][row]
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
@@ -495,33 +656,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             ti[lcol * TL_LD + lq + 4 * r] = xi[r];
           }
         }
-        __syncthreads();  // (C)
         STAMP(7);
-        // ---- trailing tiles (P >= Q > jb): T -= L[P][jb] L[Q][jb]^H
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-          if (!live[sl] || tQ[sl] <= jb) continue;
-          const double* ar = PanR + tP[sl] * TL_TILE;
-          const double* ai = PanI + tP[sl] * TL_TILE;
-          const double* br = PanR + tQ[sl] * TL_TILE;
-          const double* bi = PanI + tQ[sl] * TL_TILE;
-          // T -= L_P L_Q^H, three real products: P1 = re re', P2 = im im', P3 = (re+im)(im'-re');
-          // Re -= P1 + P2,  Im += P3 + P1 - P2  (P3 accumulates straight into the imaginary part)
-          d4 p1 = (d4){0, 0, 0, 0}, p2 = (d4){0, 0, 0, 0};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const int o = (4 * ks + lq) * TL_LD + lcol;
-            const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];
-            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lR, p1, 0, 0, 0);
-            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, lI, p2, 0, 0, 0);
-            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, lI - lR, accI[sl], 0, 0, 0);
-          }
-          accR[sl] = accR[sl] - (p1 + p2);
-          accI[sl] = accI[sl] + (p1 - p2);
-        }
-        STAMP(8);
-        // (barrier A of the next panel orders these LDS reads before the next panel's writes)
+        __syncthreads();  // (C) panel jb published
       }
+#undef TRAILING_UPDATE
       __syncthreads();  // end of factorisation
       STAMP(3);
 
@@ -595,7 +733,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
 // Frames bucketed by the number of tile rows of their system (see LsArgs::cls).
 __device__ inline int frame_class(int n) {
   const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
-  return nt <= 8 ? 0 : nt == 9 ? 1 : nt == 10 ? 2 : nt == 11 ? 3 : nt <= TL_NTMAX ? 4 : 5;
+  return nt <= 8 ? 0 : nt == 9 ? 1 : nt == 10 ? 2 : nt == 11 ? 3 : nt == 12 ? 4 : nt <= TL_NTMAX ? 5 : LS_BIG_CLASS;
 }
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArgs A) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -605,7 +743,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArg
     const long long lo = (c - wl - 1 > 0) ? (c - wl - 1) : 0;
     for (long long ch = lo >> 10; ch <= ((c + wl) >> 10); ++ch) A.zflag[ch] = 1;
   }
-  for (int c = 0; c < 6; ++c) {   // one atomic per wave and class, positions from the ballot
+  for (int c = 0; c < LS_NCLS; ++c) {   // one atomic per wave and class, positions from the ballot
     const unsigned long long m = __ballot(cl == c);
     if (m == 0ull) continue;
     int base = 0;
@@ -655,9 +793,11 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
     const int item = nxt;                                                                \
     __syncthreads();                                                                     \
     if (item >= A.cls[C]) break;                                                         \
-    tile_frame<NSV>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);     \
+    if (A.mode == 0) tile_frame<NSV, 0>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);   \
+    else tile_frame<NSV, 1>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);               \
   }
-  RUN_CLASS(12, 4)   // 78 / 91 tiles
+  RUN_CLASS(12, 5)   // 91 tiles
+  RUN_CLASS(10, 4)   // 78 tiles
   RUN_CLASS(9, 3)    // 66 tiles
   RUN_CLASS(7, 2)    // 55 tiles
   RUN_CLASS(6, 1)    // 45 tiles
