@@ -131,23 +131,33 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
 }
 
 
-// ---- diagonal tile, ONE wave, on the matrix cores -------------------------------------------------------------
-// The same 2x2-block-pivot elimination as diag_coop, but the wave that owns the diagonal tile keeps it (and the
-// inverse in the making) in MFMA accumulator layout — lane (lq, lcol), register r <-> entry (lq + 4 r, lcol) — and
-// every elimination step is a complex rank-2 update, i.e. a real 16x16x4 product: ONE v_mfma_f64_16x16x4_f64 per
-// real/imaginary plane,
+// ---- diagonal tile on the matrix cores, two waves, no workgroup barrier ----------------------------------------
+// The same 2x2-block-pivot elimination as diag_coop, but the tile (and the inverse in the making) stays in MFMA
+// accumulator layout — lane (lq, lcol), register r <-> entry (lq + 4 r, lcol) — and every elimination step is a
+// complex rank-2 update, i.e. a real 16x16x4 product: ONE v_mfma_f64_16x16x4_f64 per real / imaginary plane,
 //     T[i][k] -= a1[i] c1[k] + a2[i] c2[k],   a_s = columns j, j+1 of the tile,  c = P^-1 [conj a1[k]; conj a2[k]],
 //     Z[i][k] -= a1[i] d1[k] + a2[i] d2[k],   d = P^-1 [Z[j][k]; Z[j+1][k]]          (forward elimination on [L | I]),
 // with the operand (row i, k-index kk) = (a1R, a1I, a2R, a2I)[kk] and the products' signs folded into the second
-// operand.  Rows / columns that are finished (i, k < j+2) are masked out of the operands.  No workgroup barrier: the
-// pivot block is read with v_readlane, the two columns and the two rows of Z travel through 1 KB of wave-private
-// LDS, and the other seven waves of the workgroup are free to run trailing updates meanwhile (look-ahead).
-//   R, I     the tile (lower triangle used)
-//   cs       wave-private LDS, 256 doubles
-//   Wt*      (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j],  W = L^-1;     Ld* (if want_L): L[i][j] at [i*TL_LD + j]
+// operand.  Rows / columns that are finished (i, k < j+2) are masked out of the operands.
+// The work is a chain of dependent scalar-ish steps, so it is split over two waves that run as a pipeline:
+//   diag_D  (the wave that owns the tile)  eliminates the tile itself and POSTS, per step, the two pivot columns and
+//           the pivot block to LDS, then raises a step counter (release);
+//   diag_Z  (a helper wave)  follows one step behind (acquire), applies the same eliminations to the identity and
+//           finishes rows j, j+1 of W = L^-1 with the block's own Cholesky factor.
+// Neither touches a workgroup barrier, so the other waves run their trailing updates meanwhile (look-ahead).
+// The tile is Hermitian and BOTH triangles are kept up to date, so row j of the tile, T[j][k] = conj(a1[k]), is at
+// once the conjugated column the second operand is made of and (conjugated back) the first operand; a row sits in
+// sixteen lanes of one register, and ds_bpermute hands it to every lane without a round trip through LDS memory.
+//   post     LDS: [8 steps][2 rows][16][re, im]  rows j, j+1 of the tile at step j/2 (they contain the pivot block)
+//   Wt*      (W^H)[k][j] = conj(W[j][k]) at [k*TL_LD + j];     Ld* (want_L): L[i][j] at [i*TL_LD + j], rows > j+1 only
 //   dref / nvalid / fault: as for diag_coop
+#define DGP_DOUBLES 512
 __device__ inline double rdlane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double bperm(double v, int byte_addr) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
 }
 __device__ inline double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -156,101 +166,139 @@ __device__ inline double rsqrt_nr(double x) {
   return y;
 }
 
-__device__ __attribute__((always_inline)) inline void diag_wave(d4 R, d4 I, double* cs, double* WtR, double* WtI,
-                                                                 double* LdR, double* LdI, bool want_L,
-                                                                 const double* dref, int nvalid, int* fault) {
+__device__ __attribute__((always_inline)) inline void diag_D(d4 R, d4 I, double* post, int* flag, int flag_base,
+                                                              double* dump, double* LdR, double* LdI, bool want_L) {
   const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
   const bool hi = lq >= 2, odd = (lq & 1) != 0;   // which of (c1, c2) / (re, im) this lane's operand entry is
-  double* col2 = cs;         // [16][4]  a1R a1I a2R a2I of row i
-  double* zrow = cs + 64;    // [16][4]  Z[j][k] re im, Z[j+1][k] re im of column k
-  double* dump = cs + 128;   // [64][2]  where the lanes that hold nothing of a column / row store instead (no branch)
+  const double sg = hi ? 1.0 : -1.0;
+#pragma unroll
+  for (int j = 0; j < 16; j += 2) {
+    const int j1 = j + 1, st = j >> 1, rg = j >> 2;   // rows j and j+1 sit in the same register
+    // ---- pivot block (wave-uniform, scalar registers)
+    double p = rdlane(R[rg], (j & 3) * 16 + j);
+    const double r = rdlane(R[rg], (j1 & 3) * 16 + j1);
+    const double qr = rdlane(R[rg], (j1 & 3) * 16 + j), qi = rdlane(I[rg], (j1 & 3) * 16 + j);
+    // ---- rows j, j+1 to every lane: X = the row this lane's operand entry belongs to, Y = the other one
+    const int aX = (((hi ? j1 : j) & 3) * 16 + lcol) * 4, aY = (((hi ? j : j1) & 3) * 16 + lcol) * 4;
+    const double Xr = bperm(R[rg], aX), Xi = bperm(I[rg], aX), Yr = bperm(R[rg], aY), Yi = bperm(I[rg], aY);
+    // ---- post the two rows for diag_Z (the lanes that hold them; the others write to their dump slot)
+    {
+      const bool first = lq == (j & 3), hold = first || (lq == (j1 & 3));
+      double* dst = hold ? (post + st * 64 + (first ? 0 : 32) + lcol * 2) : (dump + lane * 2);
+      dst[0] = R[rg];
+      dst[1] = I[rg];
+    }
+    double det = p * r - (qr * qr + qi * qi);
+    p = (p > 0.0) ? p : 1.0;
+    det = (det > 0.0) ? det : 1.0;   // legitimately only at the RHS position of the last tile (residual ~ 0)
+    double dinv = __builtin_amdgcn_rcp(det);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    if (j < 14) {
+      // P^-1 [x1; x2] = ( [ r x1 - conj(q) x2 ;  p x2 - q x1 ] ) / det,  x_t[k] = conj(a_t[k]) = T[j+t-1][k].
+      // A lane needs ONE real entry of one of the two:  res = u X - v Y,  (u, X, v, Y) = (r, x1, conj q, x2) for c1
+      // (lq < 2), (p, x2, q, x1) for c2 (lq >= 2);  second operand of the real-plane product: odd ? Im res : -Re res,
+      // of the imaginary plane: odd ? -Re res : -Im res.  Finished columns (k < j+2) get a zero operand; the first
+      // operand (row i = lcol) is a_X[i] = conj(X): (Re, -Im) by `odd`, zero for finished rows.
+      const double m = (lcol >= j + 2) ? dinv : 0.0;
+      const double u = (hi ? p : r) * m, vr = qr * m, vi = (qi * sg) * m;
+      double asel = odd ? -Xi : Xr;
+      asel = (lcol >= j + 2) ? asel : 0.0;
+      const double rr_ = fma(u, Xr, -fma(vr, Yr, -(vi * Yi))), ri_ = fma(u, Xi, -fma(vr, Yi, vi * Yr));
+      const double bre = odd ? ri_ : -rr_, bim = odd ? -rr_ : -ri_;
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bre, R, 0, 0, 0);
+      I = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bim, I, 0, 0, 0);
+    }
+    __hip_atomic_store(flag, flag_base + st + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (want_L) {   // (last tile of a frame only; only rows beyond the block are ever read: the RHS row)
+      const double a1r = hi ? Yr : Xr, a1i = hi ? -Yi : -Xi, a2r = hi ? Xr : Yr, a2i = hi ? -Xi : -Yi;   // row i = lcol
+      const double i11 = rsqrt_nr(p);
+      const double l21r = qr * i11, l21i = qi * i11;
+      double s22 = r - (l21r * l21r + l21i * l21i);
+      s22 = (s22 > 0.0) ? s22 : 1.0;
+      const double i22 = rsqrt_nr(s22);
+      const double l1r = a1r * i11, l1i = a1i * i11;
+      const double l2r = (a2r - (l1r * l21r + l1i * l21i)) * i22, l2i = (a2i - (l1i * l21r - l1r * l21i)) * i22;
+      LdR[lcol * TL_LD + j] = l1r;   LdI[lcol * TL_LD + j] = l1i;
+      LdR[lcol * TL_LD + j1] = l2r;  LdI[lcol * TL_LD + j1] = l2i;
+    }
+  }
+}
+
+// zs: 64 doubles of wave-private LDS (per-row factors)
+__device__ __attribute__((always_inline)) inline void diag_Z(const double* post, int* flag, int flag_base, double* zs,
+                                                              double* WtR, double* WtI, const double* dref, int nvalid,
+                                                              int* fault) {
+  const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
+  const bool hi = lq >= 2, odd = (lq & 1) != 0;
+  const double sg = hi ? 1.0 : -1.0;
+  const int offA = (hi ? 32 : 0) + lcol * 2 + (odd ? 1 : 0);   // this lane's first-operand entry inside a step's rows
+  double* facrow = zs;   // [16][4]  per row of W: {iota, lambda re, lambda im, kappa}
   d4 ZR, ZI = (d4){0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) ZR[r] = (lq + 4 * r == lcol) ? 1.0 : 0.0;
-  const double dv = dref[lcol];   // original diagonal, lane k holds position k
-  int bad = 0;
 #pragma unroll
-  for (int j = 0; j < 16; j += 2) {
-    const int j1 = j + 1;
-    // ---- pivot block (wave-uniform, scalar registers)
-    double p = rdlane(R[j >> 2], (j & 3) * 16 + j);
-    const double r = rdlane(R[j1 >> 2], (j1 & 3) * 16 + j1);
-    const double qr = rdlane(R[j1 >> 2], (j1 & 3) * 16 + j), qi = rdlane(I[j1 >> 2], (j1 & 3) * 16 + j);
+  for (int j = 0; j < 14; j += 2) {
+    const int j1 = j + 1, st = j >> 1, rg = j >> 2;
+    // rows j, j+1 of Z (final after the previous step) to every lane
+    const int aX = (((hi ? j1 : j) & 3) * 16 + lcol) * 4, aY = (((hi ? j : j1) & 3) * 16 + lcol) * 4;
+    const double Xr = bperm(ZR[rg], aX), Xi = bperm(ZI[rg], aX), Yr = bperm(ZR[rg], aY), Yi = bperm(ZI[rg], aY);
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_base + st + 1)
+      __builtin_amdgcn_s_sleep(1);
+    const double* rows = post + st * 64;   // T[j][k] at [2k], T[j+1][k] at [32 + 2k]
+    double p = rows[2 * j];
+    const double qr = rows[2 * j1], qi = -rows[2 * j1 + 1], r = rows[32 + 2 * j1];   // q = T[j+1][j] = conj(T[j][j+1])
     double det = p * r - (qr * qr + qi * qi);
-    bad |= (int)(j < nvalid) & (int)!(p > PIVOT_TOL * rdlane(dv, j));
-    bad |= (int)(j1 < nvalid) & (int)!(det > PIVOT_TOL * rdlane(dv, j1) * p);
     p = (p > 0.0) ? p : 1.0;
-    det = (det > 0.0) ? det : 1.0;   // legitimately only at the RHS position of the last tile (residual ~ 0)
-    // ---- columns j, j+1 of the tile and rows j, j+1 of Z -> LDS, indexed by row / by column.  Every lane stores:
-    //      the holders to the table, the others to their dump slot.
-    {
-      double* dst = (lcol == j) ? (col2 + lq * 4) : (lcol == j1) ? (col2 + lq * 4 + 2) : (dump + lane * 2 - 16 * 0);
-      const int st = (lcol == j || lcol == j1) ? 16 : 0;   // row stride 4 doubles, rows lq + 4 rr
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) { dst[rr * st] = R[rr]; dst[rr * st + 1] = I[rr]; }
-      double* dz = (lq == (j & 3)) ? (zrow + lcol * 4) : (lq == (j1 & 3)) ? (zrow + lcol * 4 + 2) : (dump + lane * 2);
-      const bool first = lq == (j & 3);
-      dz[0] = first ? ZR[j >> 2] : ZR[j1 >> 2];
-      dz[1] = first ? ZI[j >> 2] : ZI[j1 >> 2];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double a1r = col2[lcol * 4 + 0], a1i = col2[lcol * 4 + 1], a2r = col2[lcol * 4 + 2], a2i = col2[lcol * 4 + 3];
-    const double z1r = zrow[lcol * 4 + 0], z1i = zrow[lcol * 4 + 1], z2r = zrow[lcol * 4 + 2], z2i = zrow[lcol * 4 + 3];
-    double asel = col2[lcol * 4 + lq];
+    det = (det > 0.0) ? det : 1.0;
+    double dinv = __builtin_amdgcn_rcp(det);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    double asel = rows[offA];            // a_X[i] = conj(T[row][i]):  (Re, -Im) by `odd`
+    asel = odd ? -asel : asel;
     asel = (lcol >= j + 2) ? asel : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    if (j < 14) {
-      double dinv = __builtin_amdgcn_rcp(det);
-      dinv = dinv * fma(-det, dinv, 2.0);
-      dinv = dinv * fma(-det, dinv, 2.0);
-      // P^-1 [x1; x2] = ( [ r x1 - conj(q) x2 ;  p x2 - q x1 ] ) / det.  A lane needs ONE real entry of one of the two:
-      //   res = u X - v Y,   (u, X, v, Y) = (r, x1, conj q, x2) for c1 (lq < 2),  (p, x2, q, x1) for c2 (lq >= 2),
-      //   second operand of the real-plane product: odd ? Im res : -Re res;  imaginary plane: odd ? -Re res : -Im res
-      const double u = (hi ? p : r) * dinv, vr = qr * dinv, vi = (hi ? qi : -qi) * dinv;
-      double bre, bim, zre, zim;
-      {   // D: x = conj(a)
-        const double Xr = hi ? a2r : a1r, Xi = hi ? -a2i : -a1i, Yr = hi ? a1r : a2r, Yi = hi ? -a1i : -a2i;
-        const double rr_ = fma(u, Xr, -fma(vr, Yr, -(vi * Yi))), ri_ = fma(u, Xi, -fma(vr, Yi, vi * Yr));
-        bre = odd ? ri_ : -rr_;
-        bim = odd ? -rr_ : -ri_;
-        if (lcol < j + 2) { bre = 0.0; bim = 0.0; }   // finished columns stay as they are
-      }
-      {   // Z: x = rows j, j+1 of Z
-        const double Xr = hi ? z2r : z1r, Xi = hi ? z2i : z1i, Yr = hi ? z1r : z2r, Yi = hi ? z1i : z2i;
-        const double rr_ = fma(u, Xr, -fma(vr, Yr, -(vi * Yi))), ri_ = fma(u, Xi, -fma(vr, Yi, vi * Yr));
-        zre = odd ? ri_ : -rr_;
-        zim = odd ? -rr_ : -ri_;
-      }
-      R = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bre, R, 0, 0, 0);
-      I = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bim, I, 0, 0, 0);
-      ZR = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, zre, ZR, 0, 0, 0);
-      ZI = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, zim, ZI, 0, 0, 0);
-    }
-    // ---- the block's own Cholesky factor [[l11, 0], [l21, l22]]: rows j, j+1 of W, columns j, j+1 of L
+    const double u = (hi ? p : r) * dinv, vr = qr * dinv, vi = (qi * sg) * dinv;
+    const double rr_ = fma(u, Xr, -fma(vr, Yr, -(vi * Yi))), ri_ = fma(u, Xi, -fma(vr, Yi, vi * Yr));
+    const double zre = odd ? ri_ : -rr_, zim = odd ? -rr_ : -ri_;
+    ZR = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, zre, ZR, 0, 0, 0);
+    ZI = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, zim, ZI, 0, 0, 0);
+  }
+  // ---- every pivot block's own Cholesky factor [[l11, 0], [l21, l22]] at once (lane b <-> block b), the collapsed-
+  //      pivot check, and the rows of W:  W[j] = Z[j] / l11,  W[j+1] = (Z[j+1] - l21 W[j]) / l22
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_base + 8) __builtin_amdgcn_s_sleep(1);
+  {
+    const int b = lane & 7, j = 2 * b;
+    const double* rows = post + b * 64;
+    double p = rows[2 * j];
+    const double qr = rows[2 * (j + 1)], qi = -rows[2 * (j + 1) + 1], r = rows[32 + 2 * (j + 1)];
+    const double det = p * r - (qr * qr + qi * qi);
+    const bool bad = (j < nvalid && !(p > PIVOT_TOL * dref[j])) || (j + 1 < nvalid && !(det > PIVOT_TOL * dref[j + 1] * p));
+    p = (p > 0.0) ? p : 1.0;
     const double i11 = rsqrt_nr(p);
     const double l21r = qr * i11, l21i = qi * i11;
     double s22 = r - (l21r * l21r + l21i * l21i);
     s22 = (s22 > 0.0) ? s22 : 1.0;
     const double i22 = rsqrt_nr(s22);
-    {   // column k = lcol of W rows j, j+1 (zero above the diagonal because Z is lower triangular); the four lanes
-        // of a column write the same values
-      const double w1r = z1r * i11, w1i = z1i * i11;
-      const double w2r = (z2r - (l21r * w1r - l21i * w1i)) * i22, w2i = (z2i - (l21r * w1i + l21i * w1r)) * i22;
-      WtR[lcol * TL_LD + j] = w1r;   WtI[lcol * TL_LD + j] = -w1i;
-      WtR[lcol * TL_LD + j1] = w2r;  WtI[lcol * TL_LD + j1] = -w2i;
-    }
-    if (want_L) {   // (last tile of a frame only) row i = lcol of L columns j, j+1
-      const int i = lcol;
-      double l1r = a1r * i11, l1i = a1i * i11;
-      double l2r = (a2r - (l1r * l21r + l1i * l21i)) * i22, l2i = (a2i - (l1i * l21r - l1r * l21i)) * i22;
-      if (i == j) { l1r = p * i11; l1i = 0.0; l2r = 0.0; l2i = 0.0; }
-      else if (i == j1) { l1r = l21r; l1i = l21i; l2r = s22 * i22; l2i = 0.0; }
-      else if (i < j) { l1r = 0.0; l1i = 0.0; l2r = 0.0; l2i = 0.0; }
-      LdR[i * TL_LD + j] = l1r;   LdI[i * TL_LD + j] = l1i;
-      LdR[i * TL_LD + j1] = l2r;  LdI[i * TL_LD + j1] = l2i;
-    }
+    // W_row = (Z_row - lambda (kappa Z_partner)) iota:  first row of a block {i11, 0, 0, 0}, second {i22, l21, i11}
+    facrow[j * 4 + 0] = i11; facrow[j * 4 + 1] = 0.0; facrow[j * 4 + 2] = 0.0; facrow[j * 4 + 3] = 0.0;
+    facrow[j * 4 + 4] = i22; facrow[j * 4 + 5] = l21r; facrow[j * 4 + 6] = l21i; facrow[j * 4 + 7] = i11;
+    if (__ballot(bad) != 0ull && lane == 0) atomicAdd(fault, 1);
   }
-  if (bad && lane == 0) atomicAdd(fault, 1);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lq + 4 * r;
+    const double io = facrow[row * 4], lr = facrow[row * 4 + 1], li = facrow[row * 4 + 2], ka = facrow[row * 4 + 3];
+    // partner row (row ^ 1) of the same column sits in lane ^ 16, same register
+    const double pr = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(ZR[r]), 0x401F),
+                                       __builtin_amdgcn_ds_swizzle(__double2loint(ZR[r]), 0x401F));
+    const double pi = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(ZI[r]), 0x401F),
+                                       __builtin_amdgcn_ds_swizzle(__double2loint(ZI[r]), 0x401F));
+    const double wpr = ka * pr, wpi = ka * pi;
+    const double wr = (ZR[r] - (lr * wpr - li * wpi)) * io, wi = (ZI[r] - (lr * wpi + li * wpr)) * io;
+    WtR[lcol * TL_LD + row] = wr;
+    WtI[lcol * TL_LD + row] = -wi;
+  }
 }
 
 

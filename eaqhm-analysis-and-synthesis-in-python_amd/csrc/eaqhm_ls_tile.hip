@@ -578,7 +578,12 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       // Right-looking tile Cholesky with look-ahead.  Stage jb: the trailing update with panel jb-1 — the diagonal tile
       // (jb, jb) first, whose owner then factorises and inverts it on its own (diag_wave: one wave, matrix cores, no
       // workgroup barrier) while the other waves are still in their updates — barrier — panel jb — barrier.
-      double* dws = Dc;   // wave-private scratch of the diagonal step (only one wave is in it at a time)
+      double* post = Dc;                 // what diag_D posts for diag_Z (Dc and Zc are contiguous: 1088 doubles)
+      double* dumpD = Dc + DGP_DOUBLES;  // [128] dump slots of diag_D
+      double* zs = dumpD + 128;          // [256] row exchange, dump slots and row factors of diag_Z
+      int* dflag = (int*)(zs + 256);     // step counter of the diagonal pipeline
+      if (tid == 0) *dflag = 0;          // (region U held the last basis chunk until the barrier that ended the Gramian)
+      __syncthreads();
 #define TRAILING_UPDATE(sl)                                                                         \
   {                                                                                                 \
     const double* ar = PanR + tP[sl] * TL_TILE;                                                     \
@@ -609,9 +614,15 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           mine = true;
         }
         // real unknowns: every position but, in the last tile, the signal column `is` and the padding behind it
+#ifndef EAQHM_EXPERIMENT_NODIAG   /* (timing experiment: what a frame costs without the diagonal steps; wrong results) */
         if (mine)
-          diag_wave(Rt, It, dws, WtR + jb * TL_TILE, WtI + jb * TL_TILE, LdR, LdI, jb == nt - 1, dorig + 16 * jb,
-                    (jb == nt - 1) ? is : 16, uni(A.fault));
+          diag_D(Rt, It, post, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
+        else if (wave == (((jb * (jb + 1) / 2 + jb) % TL_CW) ^ 1))   // the owner's neighbour builds the inverse
+          diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
+                 (jb == nt - 1) ? is : 16, uni(A.fault));
+#else
+        if (mine) asm volatile("" ::"v"(Rt[0]), "v"(It[0]));
+#endif
         STAMP(10);
         if (jb > 0) {
 #pragma unroll

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libeaqhm_hip.so")
+# EAQHM_LIB: A/B measurements with an alternative build of the same library (tools/); the product default is in-tree
+LIB_PATH = os.environ.get("EAQHM_LIB") or os.path.join(_HERE, "csrc", "libeaqhm_hip.so")
 
 # every symbol include/eaqhm_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
