@@ -166,6 +166,17 @@ __device__ inline double rsqrt_nr(double x) {
   return y;
 }
 
+// Bounded wait on the pipeline's step counter: every wave reaches an exit even if the protocol were broken (the frame
+// is then counted DIAG_STUCK times in the fault counter and the host raises).
+#define DIAG_STUCK (1 << 20)
+__device__ inline bool spin_until(int* flag, int target) {
+  for (int spins = 0; spins < (1 << 16); ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
 __device__ __attribute__((always_inline)) inline void diag_D(d4 R, d4 I, double* post, int* flag, int flag_base,
                                                               double* dump, double* LdR, double* LdI, bool want_L) {
   const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
@@ -234,6 +245,7 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
   const double sg = hi ? 1.0 : -1.0;
   const int offA = (hi ? 32 : 0) + lcol * 2 + (odd ? 1 : 0);   // this lane's first-operand entry inside a step's rows
   double* facrow = zs;   // [16][4]  per row of W: {iota, lambda re, lambda im, kappa}
+  int stuck = 0;
   d4 ZR, ZI = (d4){0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) ZR[r] = (lq + 4 * r == lcol) ? 1.0 : 0.0;
@@ -243,8 +255,7 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
     // rows j, j+1 of Z (final after the previous step) to every lane
     const int aX = (((hi ? j1 : j) & 3) * 16 + lcol) * 4, aY = (((hi ? j : j1) & 3) * 16 + lcol) * 4;
     const double Xr = bperm(ZR[rg], aX), Xi = bperm(ZI[rg], aX), Yr = bperm(ZR[rg], aY), Yi = bperm(ZI[rg], aY);
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_base + st + 1)
-      __builtin_amdgcn_s_sleep(1);
+    if (!spin_until(flag, flag_base + st + 1)) stuck = 1;
     const double* rows = post + st * 64;   // T[j][k] at [2k], T[j+1][k] at [32 + 2k]
     double p = rows[2 * j];
     const double qr = rows[2 * j1], qi = -rows[2 * j1 + 1], r = rows[32 + 2 * j1];   // q = T[j+1][j] = conj(T[j][j+1])
@@ -265,7 +276,8 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
   }
   // ---- every pivot block's own Cholesky factor [[l11, 0], [l21, l22]] at once (lane b <-> block b), the collapsed-
   //      pivot check, and the rows of W:  W[j] = Z[j] / l11,  W[j+1] = (Z[j+1] - l21 W[j]) / l22
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_base + 8) __builtin_amdgcn_s_sleep(1);
+  if (!spin_until(flag, flag_base + 8)) stuck = 1;
+  if (stuck && lane == 0) atomicAdd(fault, DIAG_STUCK);
   {
     const int b = lane & 7, j = 2 * b;
     const double* rows = post + b * 64;

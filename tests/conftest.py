@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# The oracle's many small BLAS calls crawl when every one of them fans out over all the cores of a big host (the GPU
+# box has 256): keep the thread pools small for the whole test session.
+try:
+    from threadpoolctl import threadpool_limits
+    _blas_limit = threadpool_limits(limits=min(8, os.cpu_count() or 1))
+except Exception:      # threadpoolctl missing: the tests still run, only slower
+    _blas_limit = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test (still part of the default CPU suite)")

@@ -11,8 +11,11 @@ eng = DeviceAnalysis(s, s, plan, 160, 5)
 eng.ctx.set_option(2, 1)
 eng.run()
 d = eng.ctx.debug_read()
-names = ["setup+A1", "build: barrier wait", "contraction", "(fact tail)", "backsubst", "record", "publish diag", "trsm", "update", "-", "diag_coop", "build: items (thread 0)", "build: rows (thread 0)"]
+names = ["setup + slot preparation", "build: barrier wait", "contraction (a>=1) / closed-form fill (a=0)", "(end of factorisation)",
+         "back substitution", "record", "wait at barrier A (the diagonal pipeline of another wave)", "panel (X = T W^H)",
+         "trailing update (own tiles)", "-", "barrier C wait + next diagonal tile's update + diagonal role (when wave 0 has one)",
+         "-", "build: basis rows (wave 0)"]
 tot = sum(d[:13])
 for n, v in zip(names, d):
-    print("%-20s %12d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
+    print("%-90s %14d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
 print("workload", wl, "frames", eng.n_ls_frames, "cycles/frame", tot / max(1, eng.n_ls_frames), "SRER", [float(v) for v in eng.SRER])
