@@ -9,7 +9,7 @@
 // functions.py:521-530 are the leading 2Kc x 2Kc block of  Y^H Y  and the right-hand side is its last column.
 // Factorising  Y^H Y  WITH that last row/column leaves conj(L^-1 rhs) in the last row: the forward substitution
 // costs nothing.  Every 16x16 complex tile of Y^H Y is one MFMA accumulation over time, owned by one wave
-// (tile x = P(P+1)/2+Q -> wave x%8, slot x/8) from the first sample to the last back-substitution step.
+// (tiles numbered column by column, tile x -> wave x%8, slot x/8) from the first sample to the last back-substitution step.
 //
 //   A1     per-slot set-up: zero-count look-ups decide whether the slot's window has a gap; gap-free slots need
 //          only their centre values, the others are bridged into per-workgroup scratch rows
@@ -331,19 +331,31 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     STAMP(0);
 
     // system tiles of this wave
-    constexpr bool M3 = (NS <= 7);   // register budget: a third accumulator per tile only for the smaller frames
-    d4 accR[NS], accI[NS], acc3[M3 ? NS : 1];
+    // Three real products per complex one need a third accumulator per tile: the first NM3 tiles of a wave.  Register
+    // budget: every tile of the small frames, none beyond 7 slots (tried: 6 of 9 and 4 of 10 slots, 192 accumulator
+    // VGPRs like the 12-slot budget — the extra spills cost more than the 17 % / 10 % fewer MFMAs gain: 1.23 M vs
+    // 1.27 M frames/s on the 60 s workload).
+    constexpr int NM3 = (NS <= 7) ? NS : 0;
+    d4 accR[NS], accI[NS], acc3[NM3 ? NM3 : 1];
     int tP[NS], tQ[NS];
     bool live[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
       accR[sl] = (d4){0, 0, 0, 0};
       accI[sl] = (d4){0, 0, 0, 0};
-      if (M3) acc3[sl] = (d4){0, 0, 0, 0};
+      if (sl < NM3) acc3[sl] = (d4){0, 0, 0, 0};
+      // Ownership: tiles numbered column by column, x = Q nt - Q(Q-1)/2 + (P - Q), tile x on wave x % 8, slot x / 8.
+      // The tiles of one tile column — the panel of a stage — then sit on consecutive waves, and so do the columns of
+      // the trailing matrix: both phases of every stage are balanced to within one tile per wave (the row-major
+      // numbering of round 1 put up to three panel tiles of a stage on one wave).
       const int x = sl * TL_CW + wave;
       live[sl] = x < ntiles;
       int P = 0, Q = 0;
-      sys_tile_of(live[sl] ? x : 0, P, Q);
+      if (live[sl]) {
+        int start = 0;
+        while (Q + 1 < nt && start + (nt - Q) <= x) { start += nt - Q; ++Q; }
+        P = Q + (x - start);
+      }
       tP[sl] = __builtin_amdgcn_readfirstlane(P);   // wave-uniform: scalar registers, not spill slots
       tQ[sl] = __builtin_amdgcn_readfirstlane(Q);
     }
@@ -500,9 +512,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             const double aR = Xre[rb + ca + sw], aI = Xre[rb + ca + sw + plane];
             const double bR = Xre[rb + cb + sw], bI = Xre[rb + cb + sw + plane];
             rb += 4 * ldx;
-            if constexpr (M3) {
+            if (sl < NM3) {
               accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
-              acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl], 0, 0, 0);
+              acc3[sl < NM3 ? sl : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl < NM3 ? sl : 0], 0, 0, 0);
               accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI - bR, accI[sl], 0, 0, 0);
             } else {
               accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
@@ -527,9 +539,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             naR = Xre[rb + ca + sw]; naI = Xre[rb + ca + sw + plane]; nbR = Xre[rb + cb + sw]; nbI = Xre[rb + cb + sw + plane];
           }
           __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs below
-          if constexpr (M3) {   // three real products per complex one: P1 = aR bR, P2 = aI bI, P3 = (aR+aI)(bI-bR)
+          if (sl < NM3) {   // three real products per complex one: P1 = aR bR, P2 = aI bI, P3 = (aR+aI)(bI-bR)
             accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
-            acc3[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl], 0, 0, 0);
+            acc3[sl < NM3 ? sl : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, acc3[sl < NM3 ? sl : 0], 0, 0, 0);
             accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, bI - bR, accI[sl], 0, 0, 0);
           } else {
             accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
@@ -544,9 +556,9 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       __syncthreads();
       STAMP(2);
     }
-    if constexpr (M3 && MODE == 1) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
+    if constexpr (NM3 > 0 && MODE == 1) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
+      for (int sl = 0; sl < NM3; ++sl) {
         const d4 p1 = accR[sl], p2 = acc3[sl];
         accR[sl] = p1 + p2;
         accI[sl] = accI[sl] + (p1 - p2);
@@ -617,7 +629,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
 #ifndef EAQHM_EXPERIMENT_NODIAG   /* (timing experiment: what a frame costs without the diagonal steps; wrong results) */
         if (mine)
           diag_D(Rt, It, post, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
-        else if (wave == (((jb * (jb + 1) / 2 + jb) % TL_CW) ^ 1))   // the owner's neighbour builds the inverse
+        else if (wave == (((jb * nt - jb * (jb - 1) / 2) % TL_CW) ^ 1))   // the owner's neighbour builds the inverse
           diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
                  (jb == nt - 1) ? is : 16, uni(A.fault));
 #else
