@@ -61,3 +61,28 @@ def test_config4_synthetic_60s_properties():
     plan2, eng2, fin2 = _run(s, fs, track, 3)
     assert np.array_equal(np.array(eng2.SRER), srer)
     assert np.array_equal(fin2["s_recon"], fin["s_recon"]) and np.array_equal(fin2["am"], fin["am"])
+
+
+def test_config5_60s_48khz_memory_bound():
+    """SURVEY §8f row 4 (long files): the reference keeps seven dense L x Kmax float64 arrays (60 s @48 kHz: 7 x 3.7 GB);
+    this path keeps two plus the frame-centre records.  Instead of streaming the tracks in time blocks the whole file
+    stays resident — this test pins the bound that makes that acceptable: one adaptation of BASELINE config 5
+    (2,880,000 samples, 191,936 large frames, Kmax 159) peaks below 12 GB of the 288 GB of HBM (buffers of the engine;
+    the library's own grow-only scratch — per-workgroup factor tiles and the zero counts, about 2.5 GB here — comes on top)."""
+    import torch
+    from eaqhm_amd.synth import synth_speech_int16
+    fs = 48000
+    s = synth_speech_int16(60.0, fs) / 32768.0
+    track = load_golden("prep_synth48k_60s.npz")["synth48k_60s_f0s_5ms"]
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    plan, eng, fin = _run(s, fs, track, 0)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert plan.n_frames == 191936 and plan.Kmax == 159
+    dense = 2 * plan.Kmax * plan.L * 8
+    assert dense < peak < 12e9, "peak device memory of the run: %.2f GB (dense tracks %.2f GB)" % (peak / 1e9, dense / 1e9)
+    assert len(eng.SRER) == 1 and 50 < eng.SRER[0] < 70
+    d = s - fin["s_recon"]
+    assert abs(20 * np.log10(np.std(s) / np.std(d)) - eng.SRER[0]) < 1e-9
