@@ -324,19 +324,29 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
 // row-major [row][col] (the MFMA accumulator order: lane l, register r <-> index 64 r + l); afterwards it holds
 // L[P][Q] k-major [col][row], the order in which the MFMA operand loads of later columns are coalesced.
 //
-// Left-looking: column Q first gathers  T[P][Q] - sum_{j<Q} L[P][j] L[Q][j]^H  for its tiles (MFMA, three real
-// products per complex one, operands straight from memory), then the diagonal tile is factorised and inverted in
-// LDS by the whole workgroup (diag_coop) and the panel tiles are multiplied by the inverse (MFMA) and stored.
+// Left-looking by BLOCKS of CH_W tile columns.  The factor tiles of a 48 kHz frame (2-3 MB per workgroup, 0.8 GB for the
+// grid) live in HBM, not in L2; a column-by-column left-looking update reads every tile L[P][j] once per later column —
+// nt^3/6 tile reads, 20 MB per frame, 3-6 TB per launch measured, three times what HBM delivers while the MFMAs of
+// the update would need it.  So the update is applied to CH_W columns at once:
+//   (1) block update   T[P][Q0+c] -= sum_{j<Q0} L[P][j] L[Q0+c][j]^H  for the CH_W columns of the block and all rows
+//       P >= Q0: a wave takes CH_RB rows at a time, loads each A tile L[P][j] ONCE for the four columns (the four B
+//       tiles of a j are shared by all waves: L1/L2), accumulates in registers and writes the tiles back in place;
+//   (2) the columns of the block one after another, as before, with the j-loop running over the block's own earlier
+//       columns only: the diagonal tile is factorised and inverted in LDS by the whole workgroup (diag_coop) and the
+//       panel tiles are multiplied by the inverse (MFMA) and stored k-major.
 // The right-hand side rides along as the last tile row, so the forward substitution is free; the back
 // substitution walks the tile columns from the stored factor.
-#define CH_MB 6          // tiles per wave, column and register group
+#define CH_MB 6          // tiles per wave, column and register group (single-column part)
+#define CH_W 4           // tile columns per block
+#define CH_RB 2          // tile rows per wave and register group of the block update
 #define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
 #define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32 + 16)
 
-// T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
-__device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, int nt, int Kc, int nbk,
-                                            double* lds, double* xs, int* fault) {
+// T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); D0: 16*nt doubles (original diagonal, for the
+// collapsed-pivot check); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
+__device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, double* __restrict__ D0,
+                                            int nt, int Kc, int nbk, double* lds, double* xs, int* fault) {
   const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* Dc = lds;
@@ -348,18 +358,107 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
   double* trb = LdI + TL_TILE + (size_t)wave * 2 * TL_TILE;   // this wave's transposition buffer
   double* zv = LdI + TL_TILE + 8 * 2 * TL_TILE;
   double* xv = zv + 2 * 16 * CH_NTMAX;
-  double* dref = xv + 32;   // original diagonal of the tile column being factorised
+  // original diagonal of the whole system (the collapsed-pivot check of diag_coop compares against it)
+  for (int q = tid; q < 16 * nt; q += blockDim.x) {
+    const int Qd = q >> 4, i = q & 15;
+    D0[q] = T[tile_off(Qd, Qd) + i * 16 + i];
+  }
+  __syncthreads();
 
-  for (int Q = 0; Q < nt; ++Q) {
-    // tiles P = Q + wave + 8 m of this column, in groups of CH_MB per wave (registers); the first group holds the
-    // diagonal tile, which is factorised before any panel tile is finished
+  for (int Q0 = 0; Q0 < nt; Q0 += CH_W) {
+   const int Wc = (nt - Q0 < CH_W) ? (nt - Q0) : CH_W;
+#ifdef EAQHM_EXPERIMENT_NOBLOCKUPD
+   if (false) {
+#else
+   if (Q0 > 0) {
+#endif
+    // ---- (1) block update of columns Q0 .. Q0+Wc-1 from the columns before the block.  Rows P = Q0 + wave + 8 x,
+    //      CH_RB of them per register group; two accumulators per tile (re, -im), four real products per complex one.
+    const int ngr = (nt - Q0 + 8 * CH_RB - 1) / (8 * CH_RB);
+    for (int g = 0; g < ngr; ++g) {
+      d4 cR[CH_RB][CH_W], cI[CH_RB][CH_W];
+#pragma unroll
+      for (int m = 0; m < CH_RB; ++m)
+#pragma unroll
+        for (int c = 0; c < CH_W; ++c) { cR[m][c] = (d4){0, 0, 0, 0}; cI[m][c] = (d4){0, 0, 0, 0}; }
+      const int Pg = Q0 + wave + 8 * CH_RB * g;
+      if (Pg < nt) {
+        // software-pipelined over it = 4 j + ks: the operands of step it+1 are requested before the MFMAs of step it
+        // are issued (the tiles come from L2/HBM: a round trip per step would otherwise be exposed)
+        const double* Bp[CH_W];
+        const double* Ap[CH_RB];
+#pragma unroll
+        for (int c = 0; c < CH_W; ++c) Bp[c] = T + tile_off((c < Wc) ? (Q0 + c) : Q0, 0) + lq * 16 + lcol;
+#pragma unroll
+        for (int m = 0; m < CH_RB; ++m) Ap[m] = T + tile_off((Pg + 8 * m < nt) ? (Pg + 8 * m) : Pg, 0) + lq * 16 + lcol;
+        double bR[CH_W], bI[CH_W], aR[CH_RB], aI[CH_RB];
+#pragma unroll
+        for (int c = 0; c < CH_W; ++c) { bR[c] = Bp[c][0]; bI[c] = Bp[c][256]; }
+#pragma unroll
+        for (int m = 0; m < CH_RB; ++m) { aR[m] = Ap[m][0]; aI[m] = Ap[m][256]; }
+        const int nit = 4 * Q0;
+        for (int it = 0; it < nit; ++it) {
+          double nbR[CH_W], nbI[CH_W], naR[CH_RB], naI[CH_RB];
+          {   // tile j = it/4 of a row starts 512 j doubles after tile 0; k-step ks = it%4 is 64 doubles further
+            const int nx = (it + 1 < nit) ? (it + 1) : it;
+            const size_t off = (size_t)(nx >> 2) * 512 + (size_t)(nx & 3) * 64;
+#pragma unroll
+            for (int c = 0; c < CH_W; ++c) { nbR[c] = Bp[c][off]; nbI[c] = Bp[c][off + 256]; }
+#pragma unroll
+            for (int m = 0; m < CH_RB; ++m) { naR[m] = Ap[m][off]; naI[m] = Ap[m][off + 256]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs below
+#pragma unroll
+          for (int m = 0; m < CH_RB; ++m) {
+            const int P = Pg + 8 * m;
+            if (P >= nt) continue;
+#pragma unroll
+            for (int c = 0; c < CH_W; ++c) {
+              if (c >= Wc || Q0 + c > P) continue;   // (tile above the diagonal / beyond the last column)
+              cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bR[c], cR[m][c], 0, 0, 0);
+              cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[m], bI[c], cR[m][c], 0, 0, 0);
+              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bI[c], cI[m][c], 0, 0, 0);
+              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI[m], bR[c], cI[m][c], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < CH_W; ++c) { bR[c] = nbR[c]; bI[c] = nbI[c]; }
+#pragma unroll
+          for (int m = 0; m < CH_RB; ++m) { aR[m] = naR[m]; aI[m] = naI[m]; }
+        }
+        // T[P][Q0+c] -= sum  (Re -= sum a conj(b) real part;  the second accumulator holds minus the imaginary part)
+#pragma unroll
+        for (int m = 0; m < CH_RB; ++m) {
+          const int P = Pg + 8 * m;
+          if (P >= nt) continue;
+#pragma unroll
+          for (int c = 0; c < CH_W; ++c) {
+            if (c >= Wc || Q0 + c > P) continue;
+            double* Ct = T + tile_off(P, Q0 + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int o = (lq + 4 * r) * 16 + lcol;
+              Ct[o] -= cR[m][c][r];
+              Ct[256 + o] += cI[m][c][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // the block's tiles are up to date with every column before the block
+   }
+   for (int Q = Q0; Q < Q0 + Wc; ++Q) {
+    // ---- (2) column Q: tiles P = Q + wave + 8 m, in groups of CH_MB per wave (registers); the first group holds the
+    // diagonal tile, which is factorised before any panel tile is finished.  Only the block's own earlier columns
+    // are still to be subtracted.
+    const double* dref = D0 + 16 * Q;
     const int ngroups = (nt - Q + 8 * CH_MB - 1) / (8 * CH_MB);
     for (int grp = 0; grp < ngroups; ++grp) {
       const int Pb = Q + wave + 8 * CH_MB * grp;   // this wave's first tile of the group
       d4 p1[CH_MB], p2[CH_MB], p3[CH_MB];
 #pragma unroll
       for (int m = 0; m < CH_MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
-      for (int j = 0; j < Q; ++j) {
+      for (int j = Q0; j < Q; ++j) {
         const double* Bt = T + tile_off(Q, j);
         double bR[4], bI[4];
 #pragma unroll
@@ -388,7 +487,6 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = (lq + 4 * r) * 16 + lcol;
-          if (P == Q && lq + 4 * r == lcol) dref[lcol] = Ct[o];
           const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
           const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
           p1[m][r] = cr; p3[m][r] = ci;
@@ -405,7 +503,9 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         diag_init(Zc, tid);
         __syncthreads();
         // the last tile row is the right-hand side (row 0) plus identity padding: no real unknown there
+#ifndef EAQHM_EXPERIMENT_NOCHOLDIAG
         diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid, dref, (Q == nt - 1) ? 0 : 16, fault);   // ends with a barrier
+#endif
         for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
       }
       // panel tiles: X = C W^H (three real products), stored k-major
@@ -440,6 +540,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
       }
     }
     __syncthreads();   // factor column visible to every wave; Dc / Wt reusable
+   }
   }
 
   // ---- back substitution  L^H x = y,  y = conj(row 0 of the last tile row)

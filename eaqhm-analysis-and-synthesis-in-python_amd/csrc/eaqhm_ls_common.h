@@ -97,6 +97,116 @@ __device__ inline double window_value(int blackman, int u, int N) {
   return 0.42 + 0.5 * c1 + 0.08 * c2;
 }
 
+// ---- adaptation 0: the Gramian in closed form ------------------------------------------------------------------
+// At adaptation 0 the basis columns are exp(j h theta n), h = -K..K, theta = 2 pi f0 / fs, on the symmetric grid
+// n = -wl..wl with a symmetric window (functions.py:444-455), so every entry of the three Gramian blocks depends on
+// the DIFFERENCE of the two harmonic numbers only (the blocks are Toeplitz):
+//     sum_n w^2 n^p exp(j m theta n)   =   c0[|m|]  (p = 0, real) | j sgn(m) s1[|m|]  (p = 1) | c2[|m|]  (p = 2, real),
+// 3 (2K+1) real sums of wl terms instead of a contraction over N x (2 Kc)^2, and the right-hand sides are K+1 complex
+// sums  r_p[h] = sum_n w^2 n^p s_n exp(j h theta n).  The tables are built here (pairs +-t share a rotation;
+// exp(j m theta t) advances by complex rotation and is re-seeded with an exactly evaluated value every 64 samples;
+// fixed two-level summation order), then the kernels fill their system tiles from them: no basis image, no MFMA
+// contraction for adaptation 0.
+//   tab [TZ_NQ][TB], part [NCH][TZ_NQ][TB], W2 / PA / PB [wl+1] (LDS);  win, sig: the frame's window and signal (LDS)
+#define TZ_NQ 7       // c0, s1, c2, Re r0, Im r0, Re r1, Im r1
+__device__ inline void toeplitz_tables(double* tab, double* part, double* W2, double* PA, double* PB, double* ssq,
+                                       const double* win, const double* sig, int n, int wl, double theta, int tid,
+                                       int TB, int NCH) {
+  const int mid = wl, nthr = blockDim.x;
+  for (int t = tid; t <= wl; t += nthr) {
+    const double w = win[mid + t], w2 = w * w, sp = sig[mid + t], sm = sig[mid - t];
+    W2[t] = w2;
+    PA[t] = w2 * (sp + sm);
+    PB[t] = w2 * (sp - sm);
+  }
+  __syncthreads();
+  if (tid < 64) {   // signal energy sum w^2 s^2 (fixed summation order)
+    double e = 0.0;
+    for (int t = tid; t <= wl; t += 64) {
+      const double sp = sig[mid + t], sm = sig[mid - t];
+      e += W2[t] * ((t == 0) ? sp * sp : (sp * sp + sm * sm));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (tid == 0) ssq[0] = e;
+  }
+  const int nm = 2 * n + 1, CL = (wl + NCH - 1) / NCH;
+  for (int task = tid; task < nm * NCH; task += nthr) {
+    const int ch = task / nm, m = task - ch * nm;
+    const int t0 = 1 + ch * CL, t1 = (t0 + CL - 1 < wl) ? (t0 + CL - 1) : wl;
+    const double phi = (double)m * theta;
+    double zr, zi, sr, si;
+    sincos_cw((double)t0 * phi, &zi, &zr);
+    sincos_cw(phi, &si, &sr);
+    double a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    const bool rhs = m <= n;
+    for (int t = t0; t <= t1; ++t) {
+      if (t > t0 && ((t - t0) & 63) == 0) sincos_cw((double)t * phi, &zi, &zr);   // re-seed: bounds the rotation's drift
+      const double w2 = W2[t], tt = (double)t, w2t = w2 * tt;
+      a0 = fma(w2, zr, a0);
+      a1 = fma(w2t, zi, a1);
+      a2 = fma(w2t * tt, zr, a2);
+      if (rhs) {
+        const double pa = PA[t], pb = PB[t];
+        b0 = fma(pa, zr, b0);
+        b1 = fma(pb, zi, b1);
+        b2 = fma(tt * pb, zr, b2);
+        b3 = fma(tt * pa, zi, b3);
+      }
+      const double nr = zr * sr - zi * si, ni = zr * si + zi * sr;
+      zr = nr; zi = ni;
+    }
+    double* pp = part + (size_t)(ch * TZ_NQ) * TB + m;
+    pp[0] = a0; pp[TB] = a1; pp[2 * TB] = a2;
+    pp[3 * TB] = b0; pp[4 * TB] = b1; pp[5 * TB] = b2; pp[6 * TB] = b3;
+  }
+  __syncthreads();
+  for (int q = tid; q < TZ_NQ * nm; q += nthr) {
+    const int k = q / nm, m = q - k * nm;
+    double v = 0.0;
+    for (int ch = 0; ch < NCH; ++ch) v += part[(size_t)(ch * TZ_NQ + k) * TB + m];
+    if (k < 3) v *= 2.0;                                   // the pair (+t, -t)
+    if (k == 0) v += W2[0];                                // t = 0
+    if (k == 3 && m <= n) v += W2[0] * sig[mid];
+    tab[k * TB + m] = v;
+  }
+  __syncthreads();
+}
+
+// harmonic number of basis column c (0 <= c < Kc): [negative block: -(c+1) | DC | positive block]
+__device__ inline int toeplitz_harm(int c, int n) { return (c < n) ? -(c + 1) : (c - n); }
+// Gramian entry  sum_n w^2 n^p conj(x_a) x_b  of columns a, b (p = number of slope columns among them)
+__device__ inline void toeplitz_gram(const double* tab, int TB, int p, int a, int b, int n, double& re, double& im) {
+  const int m = toeplitz_harm(b, n) - toeplitz_harm(a, n), am = (m < 0) ? -m : m;
+  re = 0.0; im = 0.0;
+  if (p == 1) im = (m < 0) ? -tab[TB + am] : tab[TB + am];
+  else re = tab[p * TB + am];
+}
+// right-hand-side row entry  sum_n w^2 n^p s_n x_b  for column b of block p (0: amplitudes, 1: slopes)
+__device__ inline void toeplitz_rhs(const double* tab, int TB, int p, int b, int n, double& re, double& im) {
+  const int h = toeplitz_harm(b, n), ah = (h < 0) ? -h : h;
+  re = tab[(3 + 2 * p) * TB + ah];
+  im = tab[(4 + 2 * p) * TB + ah];
+  if (h < 0) im = -im;                                      // r[-h] = conj r[h]
+}
+
+// entry (gi, gj) of the stacked system  Y^H Y,  Y = w [E | n E | s]  (the layout of eaqhm_ls_tile_kernel)
+__device__ inline void toeplitz_entry(const double* tab, int TB, double ssq, int gi, int gj, int n, int Kc, double& re,
+                                      double& im) {
+  re = 0.0; im = 0.0;
+  const int sigc = 2 * Kc;
+  if (gi > sigc || gj > sigc) return;                       // padding: set by the caller
+  if (gi == sigc && gj == sigc) { re = ssq; return; }
+  if (gi == sigc || gj == sigc) {                           // right-hand-side row (or its mirror column: conjugate)
+    const int c = (gi == sigc) ? gj : gi;
+    toeplitz_rhs(tab, TB, (c >= Kc) ? 1 : 0, (c >= Kc) ? c - Kc : c, n, re, im);
+    if (gj == sigc) im = -im;
+    return;
+  }
+  toeplitz_gram(tab, TB, ((gi >= Kc) ? 1 : 0) + ((gj >= Kc) ? 1 : 0), (gi >= Kc) ? gi - Kc : gi, (gj >= Kc) ? gj - Kc : gj,
+                n, re, im);
+}
+
 // Phase A1 (adaptation >= 1): one thread per active slot windows its track, bridges zero gaps
 // (functions.py:251-278: interior gaps linearly, edge gaps held; positions decided on fm, applied to fm and
 // am), forms the running sums of fm relative to the window middle and the amplitude ratios

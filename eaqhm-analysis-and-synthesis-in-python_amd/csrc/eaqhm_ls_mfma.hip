@@ -30,6 +30,7 @@ struct MfScratch {
   double* r;   // (Nmax+1) * nmax
   double* T;   // stacked padded system, 16x16 complex tiles (eaqhm_ls_chol.h)
   double* WT;  // inverse diagonal tiles
+  double* D0;  // original diagonal of the system (16 per tile row)
 };
 
 __host__ __device__ inline size_t mf_tile_doubles(int Kcmax) {
@@ -38,7 +39,7 @@ __host__ __device__ inline size_t mf_tile_doubles(int Kcmax) {
 }
 __host__ __device__ inline size_t mf_scratch_doubles(int nmax, int Nmax, int Kcmax) {
   const size_t nt = 2 * (((size_t)Kcmax + 15) / 16) + 1;
-  return 2 * (size_t)(Nmax + 1) * nmax + mf_tile_doubles(Kcmax) + nt * 2 * TL_TILE;
+  return 2 * (size_t)(Nmax + 1) * nmax + mf_tile_doubles(Kcmax) + nt * 2 * TL_TILE + nt * 16;
 }
 
 __device__ inline void tile_of(int q, int& I, int& J) {
@@ -70,6 +71,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     S.r = S.Q + (size_t)(A.Nmax + 1) * A.nmax;
     S.T = S.r + (size_t)(A.Nmax + 1) * A.nmax;
     S.WT = S.T + mf_tile_doubles(A.Kcmax);
+    S.D0 = S.WT + (2 * (((size_t)A.Kcmax + 15) / 16) + 1) * 2 * TL_TILE;
   }
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
   for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // finite everywhere (rows with weight 0)
@@ -114,6 +116,47 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     }
     __syncthreads();
 
+    if (A.mode == 0) {
+      // ---- adaptation 0: the stacked padded system straight from the Toeplitz tables (eaqhm_ls_common.h): no basis,
+      //      no contraction passes.  Work space: the chunk planes.
+      const int TB = A.Kcmax + 1, NCH = 2;
+      double* tab = Xre;                                   // [TZ_NQ][TB]
+      double* part = tab + (size_t)TZ_NQ * TB;             // [NCH][TZ_NQ][TB]
+      double* W2 = part + (size_t)NCH * TZ_NQ * TB;        // [wl+1] each
+      const int wpad = ((A.Nmax >> 1) + 8) & ~7;
+      double* PA = W2 + wpad;
+      double* PB = PA + wpad;
+      double* win = PB + wpad;                             // [N]
+      double* sig = win + ((A.Nmax + 7) & ~7);             // [N]
+      for (int t = tid; t < N; t += nt) {
+        win[t] = window_value(1, t, N);
+        sig[t] = A.s[(size_t)(c - wl) + t];
+      }
+      __syncthreads();
+      toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, n, wl, f0 * (2.0 * M_PI / A.fs), tid, TB, NCH);
+      const double ssq = sh[0];
+      const int ntiles_s = ntl * (ntl + 1) / 2;
+      for (int q = tid; q < ntiles_s * 256; q += nt) {
+        const int x = q >> 8, e = q & 255, row = e >> 4, col = e & 15;
+        int P, Q;
+        tile_of(x, P, Q);
+        double re = 0.0, im = 0.0;
+        if (P == ntl - 1) {                  // right-hand-side tile row: row 0 holds conj(rhs), the rest is padding
+          if (Q == ntl - 1) re = (row == col) ? ((row == 0) ? ssq : 1.0) : 0.0;
+          else if (row == 0) {
+            const int pb = (Q >= nbk) ? 1 : 0, b = 16 * (Q - pb * nbk) + col;
+            if (b < Kc) toeplitz_rhs(tab, TB, pb, b, n, re, im);
+          }
+        } else {
+          const int pa = (P >= nbk) ? 1 : 0, pb = (Q >= nbk) ? 1 : 0;
+          const int a = 16 * (P - pa * nbk) + row, b = 16 * (Q - pb * nbk) + col;
+          if (a < Kc && b < Kc) toeplitz_gram(tab, TB, pa + pb, a, b, n, re, im);
+          else if (P == Q && row == col) re = 1.0;          // identity padding inside the two diagonal blocks
+        }
+        double* t = S.T + tile_off(P, Q) + e;
+        t[0] = re; t[256] = im;
+      }
+    } else
     for (int pass = 0; pass < npass; ++pass) {
       d4 accR[MF_NSLOT], accI[MF_NSLOT];
       int tI[MF_NSLOT], tJ[MF_NSLOT], wsel[MF_NSLOT];
@@ -247,7 +290,9 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     }
     __syncthreads();
 
-    tile_cholesky_memory(S.T, S.WT, ntl, Kc, nbk, Xre, xs, A.fault);
+#ifndef EAQHM_EXPERIMENT_NOCHOL   /* (timing experiment: the frame without its factorisation; wrong results) */
+    tile_cholesky_memory(S.T, S.WT, S.D0, ntl, Kc, nbk, Xre, xs, A.fault);
+#endif
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
   }
 }
@@ -262,11 +307,15 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   const int nbmax = (Kcmax + 1 + 15) / 16;
   int ldx_max = 16 * nbmax + 16;
   if (ldx_max * 64 < CH_LDS_DOUBLES) ldx_max = (CH_LDS_DOUBLES / 64 + 15) & ~15;   // the factorisation reuses the chunk planes
+  // ... and so does the closed-form Gramian of adaptation 0 (tables, partial sums, window, signal)
+  const size_t tz_doubles = (size_t)3 * TZ_NQ * (Kcmax + 1) + 3 * (((A.Nmax >> 1) + 8) & ~7) + 2 * ((A.Nmax + 7) & ~7);
   const size_t fixed = (size_t)(2 * nmax + 4 * (2 * Kcmax) + 16) * sizeof(double);
   int TS = 32;
   while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 150 * 1024) TS >>= 1;
   const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
+  if ((size_t)2 * TS * ldx_max < tz_doubles)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the closed-form Gramian's work space");
   if ((size_t)2 * TS * ldx_max < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > CH_NTMAX)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the tile factorisation's work space");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -156,99 +156,9 @@ __device__ inline double scan16(double x) {
   return x;
 }
 
-// ---- adaptation 0: the Gramian in closed form ------------------------------------------------------------------
-// At adaptation 0 the basis columns are exp(j h theta n), h = -K..K, theta = 2 pi f0 / fs, on the symmetric grid
-// n = -wl..wl with a symmetric window (functions.py:444-455), so every entry of the three Gramian blocks depends on
-// the DIFFERENCE of the two harmonic numbers only (the blocks are Toeplitz):
-//     sum_n w^2 n^p exp(j m theta n)   =   c0[|m|]  (p = 0, real) | j sgn(m) s1[|m|]  (p = 1) | c2[|m|]  (p = 2, real),
-// 3 (2K+1) real sums of wl terms instead of a contraction over N x (2 Kc)^2, and the right-hand sides are K+1 complex
-// sums  r_p[h] = sum_n w^2 n^p s_n exp(j h theta n).  The tables are built here (pairs +-t share a rotation; within a
-// chunk of <= 64 samples exp(j m theta t) advances by complex rotation from an exactly evaluated seed), then every
-// wave fills its own system tiles from them: no basis image, no MFMA contraction for adaptation 0.
+// (adaptation 0: the Gramian in closed form — toeplitz_tables / toeplitz_entry in eaqhm_ls_common.h)
 #define TZ_TB 104     // table stride: m = 0 .. 2 n <= 102
 #define TZ_NCH 8      // chunks of the t range (deterministic two-level summation)
-#define TZ_NQ 7       // c0, s1, c2, Re r0, Im r0, Re r1, Im r1
-__device__ inline void toeplitz_tables(double* tab, double* part, double* W2, double* PA, double* PB, double* ssq,
-                                       const double* win, const double* sig, int n, int wl, double theta, int tid) {
-  const int mid = wl;
-  for (int t = tid; t <= wl; t += TL_THREADS) {
-    const double w = win[mid + t], w2 = w * w, sp = sig[mid + t], sm = sig[mid - t];
-    W2[t] = w2;
-    PA[t] = w2 * (sp + sm);
-    PB[t] = w2 * (sp - sm);
-  }
-  __syncthreads();
-  if (tid < 64) {   // signal energy sum w^2 s^2 (fixed summation order)
-    double e = 0.0;
-    for (int t = tid; t <= wl; t += 64) {
-      const double sp = sig[mid + t], sm = sig[mid - t];
-      e += W2[t] * ((t == 0) ? sp * sp : (sp * sp + sm * sm));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-    if (tid == 0) ssq[0] = e;
-  }
-  const int nm = 2 * n + 1, CL = (wl + TZ_NCH - 1) / TZ_NCH;
-  for (int task = tid; task < nm * TZ_NCH; task += TL_THREADS) {
-    const int ch = task / nm, m = task - ch * nm;
-    const int t0 = 1 + ch * CL, t1 = (t0 + CL - 1 < wl) ? (t0 + CL - 1) : wl;
-    const double phi = (double)m * theta;
-    double zr, zi, sr, si;
-    sincos_cw((double)t0 * phi, &zi, &zr);
-    sincos_cw(phi, &si, &sr);
-    double a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-    const bool rhs = m <= n;
-    for (int t = t0; t <= t1; ++t) {
-      const double w2 = W2[t], tt = (double)t, w2t = w2 * tt;
-      a0 = fma(w2, zr, a0);
-      a1 = fma(w2t, zi, a1);
-      a2 = fma(w2t * tt, zr, a2);
-      if (rhs) {
-        const double pa = PA[t], pb = PB[t];
-        b0 = fma(pa, zr, b0);
-        b1 = fma(pb, zi, b1);
-        b2 = fma(tt * pb, zr, b2);
-        b3 = fma(tt * pa, zi, b3);
-      }
-      const double nr = zr * sr - zi * si, ni = zr * si + zi * sr;
-      zr = nr; zi = ni;
-    }
-    double* pp = part + (size_t)(ch * TZ_NQ) * TZ_TB + m;
-    pp[0] = a0; pp[TZ_TB] = a1; pp[2 * TZ_TB] = a2;
-    pp[3 * TZ_TB] = b0; pp[4 * TZ_TB] = b1; pp[5 * TZ_TB] = b2; pp[6 * TZ_TB] = b3;
-  }
-  __syncthreads();
-  for (int q = tid; q < TZ_NQ * nm; q += TL_THREADS) {
-    const int k = q / nm, m = q - k * nm;
-    double v = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < TZ_NCH; ++ch) v += part[(size_t)(ch * TZ_NQ + k) * TZ_TB + m];
-    if (k < 3) v *= 2.0;                                   // the pair (+t, -t)
-    if (k == 0) v += W2[0];                                // t = 0
-    if (k == 3 && m <= n) v += W2[0] * sig[mid];
-    tab[k * TZ_TB + m] = v;
-  }
-  __syncthreads();
-}
-
-// entry (gi, gj) of the stacked system  Y^H Y,  Y = w [E | n E | s],  from the tables (adaptation 0)
-__device__ inline void toeplitz_entry(const double* tab, double ssq, int gi, int gj, int n, int Kc, double& re, double& im) {
-  re = 0.0; im = 0.0;
-  const int sigc = 2 * Kc;
-  if (gi > sigc || gj > sigc) return;                       // padding: set by the caller
-  auto harm = [&](int c) { const int cc = (c >= Kc) ? c - Kc : c; return (cc < n) ? -(cc + 1) : (cc - n); };
-  if (gi == sigc && gj == sigc) { re = ssq; return; }
-  if (gi == sigc || gj == sigc) {                           // right-hand-side row (or its mirror column)
-    const int c = (gi == sigc) ? gj : gi, b = (c >= Kc) ? 1 : 0, h = harm(c), ah = (h < 0) ? -h : h;
-    re = tab[(3 + 2 * b) * TZ_TB + ah];
-    im = tab[(4 + 2 * b) * TZ_TB + ah];
-    if ((h < 0) != (gj == sigc)) im = -im;                  // r[-h] = conj r[h]; the mirror column holds conj
-    return;
-  }
-  const int p = ((gi >= Kc) ? 1 : 0) + ((gj >= Kc) ? 1 : 0), m = harm(gj) - harm(gi), am = (m < 0) ? -m : m;
-  if (p == 1) im = (m < 0) ? -tab[TZ_TB + am] : tab[TZ_TB + am];
-  else re = tab[p * TZ_TB + am];
-}
 
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
 // the five budgets into one kernel body spills several hundred VGPRs).
@@ -367,7 +277,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       double* W2 = part + TZ_NCH * TZ_NQ * TZ_TB;        // [wl+1] each
       double* PA = W2 + 64 * CI_NCH / 2 + 8;
       double* PB = PA + 64 * CI_NCH / 2 + 8;
-      toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, n, wl, f0 * w1, tid);
+      toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, n, wl, f0 * w1, tid, TZ_TB, TZ_NCH);
       const double ssq = sh[0];
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
@@ -375,7 +285,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double re, im;
-          toeplitz_entry(tab, ssq, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, n, Kc, re, im);
+          toeplitz_entry(tab, TZ_TB, ssq, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, n, Kc, re, im);
           accR[sl][r] = re;
           accI[sl][r] = im;
         }

@@ -8,8 +8,15 @@ import bench
 from eaqhm_amd import hip
 from eaqhm_amd.engine import DeviceAnalysis, FramePlan
 
-alt, wl = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "synth16k_60s")
+alts, wl = sys.argv[1].split(","), (sys.argv[2] if len(sys.argv) > 2 else "synth16k_60s")
 fs, s, grid, frames, fstep = bench.load_workload(wl)
+secs = float(os.environ.get("EAQHM_PROBE_SECONDS", "0"))      # optional: only the first seconds of the workload
+if secs > 0:
+    s = s[:int(secs * fs)]
+    grid = grid[:len(np.arange(0, len(s) - 1, round(fs * 5 / 1000)))]
+    from eaqhm_amd import prologue
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
 plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
 eng = DeviceAnalysis(s, s, plan, 160, 5)
 it = eng.adaptations()
@@ -17,7 +24,7 @@ next(it); next(it)          # adaptation 0 complete, adaptation 1 enqueued (fram
 torch.cuda.synchronize()
 
 
-def time_ls(ctx, reps=5):
+def time_ls(ctx, reps=(2 if fs > 16000 else 5)):
     p = eng.plan
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     out = []
@@ -35,9 +42,10 @@ def time_ls(ctx, reps=5):
 
 
 base = time_ls(eng.ctx)
-hip._lib = None
-hip.LIB_PATH = alt
-ctx2 = hip.Context(0)
-other = time_ls(ctx2)
-print("workload %s, %d frames: default build  a=0 %.2f ms  a>=1 %.2f ms | %s  a=0 %.2f ms  a>=1 %.2f ms"
-      % (wl, eng.nf, base[0], base[1], os.path.basename(alt), other[0], other[1]))
+print("workload %s, %d frames: default build  a=0 %.2f ms  a>=1 %.2f ms" % (wl, eng.nf, base[0], base[1]))
+for alt in alts:
+    hip._lib = None
+    hip.LIB_PATH = alt
+    ctx2 = hip.Context(0)
+    other = time_ls(ctx2)
+    print("   %-40s a=0 %.2f ms  a>=1 %.2f ms" % (os.path.basename(alt), other[0], other[1]))
