@@ -310,8 +310,10 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   // ... and so does the closed-form Gramian of adaptation 0 (tables, partial sums, window, signal)
   const size_t tz_doubles = (size_t)3 * TZ_NQ * (Kcmax + 1) + 3 * (((A.Nmax >> 1) + 8) & ~7) + 2 * ((A.Nmax + 7) & ~7);
   const size_t fixed = (size_t)(2 * nmax + 4 * (2 * Kcmax) + 16) * sizeof(double);
+  // rows per chunk: as many as the LDS holds (multiples of 8 = two k-steps; fewer, longer chunks amortise the
+  // barriers and the partly filled last round of the basis build)
   int TS = 32;
-  while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 150 * 1024) TS >>= 1;
+  while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 158 * 1024) TS -= 8;
   const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
   if ((size_t)2 * TS * ldx_max < tz_doubles)
