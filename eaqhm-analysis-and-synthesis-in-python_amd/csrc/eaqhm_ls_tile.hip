@@ -17,9 +17,12 @@
 //          loaded directly, phase = running sum (16-lane DPP scan + per-slot carry); the pair shares its sincos
 //          because the negative-frequency column at u is the time-reversed positive one (functions.py:284-285);
 //          contracted with v_mfma_f64_16x16x4_f64, LDS operand reads software-pipelined one k-step ahead
-//   C      right-looking tile Cholesky: diagonal tile -> LDS -> factorised AND inverted by the whole workgroup
-//          (one thread per entry, 2x2 block pivots), panel tiles are multiplied by the inverse (MFMA) and
-//          published in LDS, trailing tiles are updated from LDS operands (MFMA); no global memory traffic
+//   B0     adaptation 0: no basis at all — the Gramian in closed form from Toeplitz tables (eaqhm_ls_common.h)
+//   C      right-looking tile Cholesky with look-ahead, 2 workgroup barriers per tile row: trailing update with the
+//          previous panel (the next diagonal tile first); its owner wave factorises that tile on the matrix cores
+//          (diag_D: 2x2 block pivots, one rank-2 MFMA per plane and step, rows handed round by ds_bpermute) while a
+//          second wave follows one step behind and builds the inverse (diag_Z) and the others finish their updates;
+//          panel tiles are multiplied by the inverse (MFMA) and published in LDS; no global memory traffic
 //   C'     back substitution from the L tiles still sitting in the owners' registers; z, x vectors in LDS
 //   D      frequency mismatch, acceptance, record row (eaqhm_ls_common.h)
 //

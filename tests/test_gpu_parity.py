@@ -656,3 +656,33 @@ def test_cli_writes_reconstruction(amd, tmp_path, sa19_golden, capsys):
     fs0, s0 = wavfile.read(wav)
     s0 = s0 / 32768.0
     assert abs(20 * np.log10(np.std(s0) / np.std(s0 - x)) - ref) < 1e-3      # float32 file, SWIPE' run by the CLI
+
+
+def test_synth16k_checksums_every_adaptation(amd):
+    """The 2 s synthetic 16 kHz fixture: record and dense-state checksums the reference left after EVERY adaptation
+    (recsum0..3, densesum0..3: sums and non-zero counts of am_recon, fm_current, s_recon_tmp), incl. the rejected one."""
+    from eaqhm_amd.engine import DeviceAnalysis
+    g = load_golden("synth16k_2s_adpt3.npz")
+    s = g["wav_int16"] / 32768.0
+    plan = _plan_for(s, 16000, g["swipe_track"])
+    eng = DeviceAnalysis(s, s, plan, 160, 3)
+    seen = {}
+
+    def hook(a, e):
+        rec = e.records[0][:plan.No_ti].cpu().numpy()
+        K = plan.Kmax
+        am, fm = e.am_cur.cpu().numpy(), e.fm_cur.cpu().numpy()
+        seen[a] = (np.count_nonzero(rec[:, :K]), rec[:, :K].sum(), rec[:, K:2 * K].sum(), rec[:, 3 * K].sum(),
+                   am.sum(), fm.sum(), e.s_hat[0].cpu().numpy().sum(), np.count_nonzero(am), np.count_nonzero(fm))
+
+    eng.run(on_adaptation=hook)
+    assert len(eng.SRER) == 4 and np.abs(np.array(eng.SRER) - g["SRER"]).max() < TOL_SRER_DB
+    for a in range(4):
+        rs, ds, got = g["recsum%d" % a], g["densesum%d" % a], seen[a]
+        assert abs(got[0] - int(rs[0])) <= 2
+        assert abs(got[1] - rs[1]) <= 1e-7 * abs(rs[1]) and abs(got[2] - rs[2]) <= 1e-7 * abs(rs[2])
+        assert abs(got[3] - rs[4]) <= 1e-7
+        assert abs(got[4] - ds[0]) <= 1e-7 * abs(ds[0])            # dense am_recon
+        assert abs(got[5] - ds[3]) <= 1e-6 * abs(ds[3])            # fm_current (derivative of the unwrapped phase)
+        assert abs(got[6] - ds[5]) <= 1e-7 * max(abs(ds[5]), 1.0)  # s_recon_tmp
+        assert abs(got[7] - int(ds[6])) <= 40 and abs(got[8] - int(ds[7])) <= 40

@@ -5,7 +5,7 @@ import numpy as np, torch
 import bench
 from eaqhm_amd.engine import DeviceAnalysis, FramePlan, run_interleaved
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-fs, s, grid, frames, fstep = bench.load_workload(1)
+fs, s, grid, frames, fstep = bench.load_workload("sa19")
 engs = []
 for _ in range(B):
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)

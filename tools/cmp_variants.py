@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from eaqhm_amd.engine import DeviceAnalysis, FramePlan
-fs, s, grid, frames, fstep = bench.load_workload(1)
+fs, s, grid, frames, fstep = bench.load_workload("sa19")
 out = {}
 for var in (2, 3):
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
