@@ -233,3 +233,23 @@ def test_swipe_on_tiled_signal_matches_prep_fixture():
     grid = prologue.resample_track(swipep(s, fs, [160, 300]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
     ref = load_golden("prep_fixtures.npz")["sa19x2_f0s_5ms"]
     assert grid.shape[0] == ref.shape[0] and np.abs(grid[:, 1] - ref[:, 1]).max() < 1e-9
+
+
+def test_bench_workloads_are_complete():
+    """bench.py's named workloads (BASELINE.json configs 2-5) find their committed pitch fixtures, and the default one
+    has the frame geometry DESIGN.md quotes (63,936 LS frames per adaptation, Kmax 59, 8-12 tile rows)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from eaqhm_amd.engine import FramePlan, ls_cost
+    for wl in ("synth16k_60s", "synth48k_60s"):
+        fs, track = bench.load_track(wl)
+        assert track.shape[1] >= 2 and track.shape[0] == 12000 and np.all(track[:, 1] > 150)
+    fs, s, grid, frames, fstep = bench.load_workload("synth16k_60s")
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    assert (plan.L, plan.n_frames, plan.Kmax) == (960000, 63936, 59)
+    nt = (2 * (2 * plan.frame_K + 1) + 1 + 15) // 16
+    assert nt.min() >= 7 and nt.max() == 12
+    flops = float(ls_cost(2 * plan.frame_wl.astype(np.int64) + 1, 2 * plan.frame_K.astype(np.int64) + 1).sum())
+    assert abs(flops - 1.306e12) / 1.306e12 < 0.01            # adaptation-0 geometry (bench sums the actual n_active per launch)
+    fs, s, track = bench.load_signal("sa19x10")
+    assert len(s) == 634880
