@@ -161,18 +161,39 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # EAQHM_BENCH_REHEARSAL=1: every rank on GPU 0, collectives staged through the host over gloo — lets a one-GPU box
+    # walk through the complete N-rank code path of this file (RCCL itself excepted); its numbers mean nothing
+    rehearsal = os.environ.get("EAQHM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("EAQHM_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the RCCL path
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from eaqhm_amd.engine import DeviceAnalysis, FramePlan, Sharding
     fs, s, grid, frames, fstep = load_workload(args.workload)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
-    shard = Sharding(rank, world, dist.group.WORLD if use_dist else None)
+    if rehearsal and use_dist:
+        class HostStaged(Sharding):
+            def _all_gather_into(self, out, part):
+                host = out.cpu()
+                dist.all_gather_into_tensor(host, part.cpu().clone(), group=self.group)
+                out.copy_(host)
+
+            def all_reduce_sum(self, t):
+                host = t.cpu()
+                dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+        shard = HostStaged(rank, world, dist.group.WORLD)
+    else:
+        shard = Sharding(rank, world, dist.group.WORLD if use_dist else None)
     eng = DeviceAnalysis(s, s, plan, 160, args.max_adpt, device_index=local, shard=shard)
 
     def barrier():
@@ -211,14 +232,14 @@ def main():
     bytes_per_launch = [float(np.sum(8 * N) + (np.sum(16 * N * n) if a > 0 else 0) + np.sum(32 * (2 * n + 1)))
                         for a, n in enumerate(n_act)]
     flops_step = sum(flops_per_launch)
-    mine = torch.tensor([dt, float(frames_done), sum(ls_ms) / 1e3, flops_step * args.steps,
-                         float(np.mean(ls_ms)) if ls_ms else 0.0, float(eng.nf)], dtype=torch.float64, device="cuda")
+    mine = [dt, float(frames_done), sum(ls_ms) / 1e3, flops_step * args.steps,
+            float(np.mean(ls_ms)) if ls_ms else 0.0, float(eng.nf)]
     if use_dist:
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        allr = torch.stack(allr).cpu().numpy()
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)      # (any backend; a few floats per rank, after the timed region)
+        allr = np.array(allr, dtype=np.float64)
     else:
-        allr = mine.cpu().numpy()[None, :]
+        allr = np.array([mine], dtype=np.float64)
     dt = float(allr[:, 0].max())
     frames_total = float(allr[:, 1].sum())
     # roofline of the dominant kernel: algorithmic flops of ALL ranks' launches / (sum of their durations / ranks),
@@ -262,6 +283,8 @@ def main():
                       "parallelism": "instants sharded x%d by LS cost; boundary records all-gathered per adaptation"
                                      % world},
            "final_srer_db": max(srer), "srer_db": srer, "roofline": roofline}
+    if rehearsal:
+        out["rehearsal"] = "all ranks on one GPU, collectives staged through the host: code-path check only"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     else:
