@@ -359,14 +359,16 @@ __device__ inline void write_record(const LsArgs& A, const double* xs, double* s
   double amax = 0.0;  // amplitude floor over the positive slots (functions.py:309)
   for (int j = tid; j < n; j += nt) {
     double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
-    amax = fmax(amax, hypot(ar, ai));
+    amax = fmax(amax, sqrt(ar * ar + ai * ai));   // (amplitudes are O(1): no overflow to guard against)
   }
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
   if ((tid & 63) == 0) sh[1 + (tid >> 6)] = amax;
   __syncthreads();
   amax = 0.0;
   for (int w = 0; w < (nt >> 6); ++w) amax = fmax(amax, sh[1 + w]);
-  const double floor_db = 20.0 * log10(amax) - 150.0;
+  // 20 log10 |a| > 20 log10 max|a| - 150  (functions.py:309, :315)  <=>  |a| > max|a| * 10^-7.5; a silent frame
+  // (max|a| = 0: -inf > -inf in the reference) accepts nothing either way
+  const double floor_mag = amax * 3.1622776601683795e-08;
   const double h = f0 / (double)(A.a_iter + 1);  // functions.py:310
   double* rec = A.records + (size_t)inst * (3 * A.Kmax + 1);
   for (int k = tid; k < 3 * A.Kmax; k += nt) rec[k] = 0.0;
@@ -375,10 +377,10 @@ __device__ inline void write_record(const LsArgs& A, const double* xs, double* s
     const int k = (A.mode == 0) ? j : mycols[j];
     double ar = xs[2 * (n + 1 + j)], ai = xs[2 * (n + 1 + j) + 1];
     double br = xs[2 * (Kc + n + 1 + j)], bi = xs[2 * (Kc + n + 1 + j) + 1];
-    double mag = hypot(ar, ai);
+    double mag = sqrt(ar * ar + ai * ai);
     double eta = 0.0;
     if (A.mode == 1) eta = A.fs / (2.0 * M_PI) * ((ar * bi - ai * br) / (mag * mag));  // functions.py:297
-    if (20.0 * log10(mag) > floor_db && fabs(eta) < h) {
+    if (mag > floor_mag && fabs(eta) < h) {
       rec[k] = mag;
       rec[2 * A.Kmax + k] = atan2(ai, ar);
       double fmv;

@@ -84,6 +84,8 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
     const int k = mycols[j];
     const long long b = (long long)c + wl, a1 = (long long)c - wl - 1;
     const int cb = (int)(b >> 10), ca = (a1 >= 0) ? (int)(a1 >> 10) : 0;
+    // (the centre values are requested together with the zero counts: one memory round trip, not two)
+    const double fmc = fm_all[(size_t)k * L + c], amc = am_all[(size_t)k * L + c];
     int zc = zloc[(size_t)k * L + b] + ((cb != ca) ? ztot[(size_t)k * zchunks + ca] : 0);
     if (a1 >= 0) zc -= zloc[(size_t)k * L + a1];
     const int g = (zc != 0 || (seeds && k == 0)) ? 1 : 0;
@@ -95,7 +97,7 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
     const size_t trk = (size_t)k * L + t0;
     ((const double**)(ci + j * CI_STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (fm_all + trk);
     ((const double**)(ci + j * CI_STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (am_all + trk);
-    if (!g) centre(j, fm_all[(size_t)k * L + c], am_all[(size_t)k * L + c]);   // (a seeded slot 0 is never gap-free)
+    if (!g) centre(j, fmc, amc);   // (a seeded slot 0 is never gap-free)
   }
   if (!__syncthreads_or(anyg)) return;
   // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
