@@ -314,6 +314,116 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
 }
 
 
+// ---- the same two-wave pipeline for a REAL symmetric positive definite tile (adaptation 0: the even / odd systems
+//      of a0_frame).  Rank-2 update of a real tile = one 16x16x4 product with two of its four k-slots used:
+//      A[i][kk] = (a1[i], a2[i], 0, 0),  B[kk][k] = -(c1[k], c2[k], 0, 0),  c = P^-1 [a1[k]; a2[k]].
+//   post: [8 steps][2 rows][16]   rows j, j+1 of the tile (symmetric: row j = column j)
+__device__ __attribute__((always_inline)) inline void diag_Dr(d4 R, double* post, int* flag, int flag_base, double* dump,
+                                                               double* Ld, bool want_L) {
+  const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
+  const bool odd = (lq & 1) != 0, used = lq < 2;
+#pragma unroll
+  for (int j = 0; j < 16; j += 2) {
+    const int j1 = j + 1, st = j >> 1, rg = j >> 2;
+    double p = rdlane(R[rg], (j & 3) * 16 + j);
+    const double r = rdlane(R[rg], (j1 & 3) * 16 + j1), q = rdlane(R[rg], (j1 & 3) * 16 + j);
+    const int aX = (((odd ? j1 : j) & 3) * 16 + lcol) * 4, aY = (((odd ? j : j1) & 3) * 16 + lcol) * 4;
+    const double X = bperm(R[rg], aX), Y = bperm(R[rg], aY);
+    {
+      const bool first = lq == (j & 3), hold = first || (lq == (j1 & 3));
+      double* dst = hold ? (post + st * 32 + (first ? 0 : 16) + lcol) : (dump + lane);
+      dst[0] = R[rg];
+    }
+    double det = p * r - q * q;
+    p = (p > 0.0) ? p : 1.0;
+    det = (det > 0.0) ? det : 1.0;   // legitimately only at the RHS position of the last tile (residual ~ 0)
+    double dinv = __builtin_amdgcn_rcp(det);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    if (j < 14) {
+      // c1 = (r x1 - q x2) / det (k-slot 0),  c2 = (p x2 - q x1) / det (k-slot 1);  X is this lane's own row
+      const bool on = used && (lcol >= j + 2);
+      const double m = on ? dinv : 0.0;
+      const double res = ((odd ? p : r) * X - q * Y) * m;
+      const double asel = on ? X : 0.0;
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, -res, R, 0, 0, 0);
+    }
+    __hip_atomic_store(flag, flag_base + st + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (want_L) {   // (last tile of a system only; only rows beyond the block are ever read: the RHS row)
+      const double a1 = odd ? Y : X, a2 = odd ? X : Y;   // row i = lcol of columns j, j+1
+      const double i11 = rsqrt_nr(p), l21 = q * i11;
+      double s22 = r - l21 * l21;
+      s22 = (s22 > 0.0) ? s22 : 1.0;
+      const double i22 = rsqrt_nr(s22);
+      const double l1 = a1 * i11, l2 = (a2 - l1 * l21) * i22;
+      Ld[lcol * TL_LD + j] = l1;
+      Ld[lcol * TL_LD + j1] = l2;
+    }
+  }
+}
+
+// zs: 64 doubles of wave-private LDS (per-row factors)
+__device__ __attribute__((always_inline)) inline void diag_Zr(const double* post, int* flag, int flag_base, double* zs,
+                                                               double* Wt, const double* dref, int nvalid, int* fault) {
+  const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
+  const bool odd = (lq & 1) != 0, used = lq < 2;
+  double* facrow = zs;   // [16][4]  per row of W: {iota, lambda, kappa, -}
+  int stuck = 0;
+  d4 Z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Z[r] = (lq + 4 * r == lcol) ? 1.0 : 0.0;
+#pragma unroll
+  for (int j = 0; j < 14; j += 2) {
+    const int j1 = j + 1, st = j >> 1, rg = j >> 2;
+    const int aX = (((odd ? j1 : j) & 3) * 16 + lcol) * 4, aY = (((odd ? j : j1) & 3) * 16 + lcol) * 4;
+    const double X = bperm(Z[rg], aX), Y = bperm(Z[rg], aY);
+    if (!spin_until(flag, flag_base + st + 1)) stuck = 1;
+    const double* rows = post + st * 32;   // T[j][k] at [k], T[j+1][k] at [16 + k]
+    double p = rows[j];
+    const double q = rows[16 + j], r = rows[16 + j1];
+    double det = p * r - q * q;
+    p = (p > 0.0) ? p : 1.0;
+    det = (det > 0.0) ? det : 1.0;
+    double dinv = __builtin_amdgcn_rcp(det);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    dinv = dinv * fma(-det, dinv, 2.0);
+    const bool on = used && (lcol >= j + 2);
+    double asel = rows[(odd ? 16 : 0) + lcol];   // a_s[i] = T[j+s-1][i]
+    asel = on ? asel : 0.0;
+    const double res = used ? ((odd ? p : r) * X - q * Y) * dinv : 0.0;
+    Z = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, -res, Z, 0, 0, 0);
+  }
+  if (!spin_until(flag, flag_base + 8)) stuck = 1;
+  if (stuck && lane == 0) atomicAdd(fault, DIAG_STUCK);
+  {
+    const int b = lane & 7, j = 2 * b;
+    const double* rows = post + b * 32;
+    double p = rows[j];
+    const double q = rows[16 + j], r = rows[16 + j + 1];
+    const double det = p * r - q * q;
+    const bool bad = (j < nvalid && !(p > PIVOT_TOL * dref[j])) || (j + 1 < nvalid && !(det > PIVOT_TOL * dref[j + 1] * p));
+    p = (p > 0.0) ? p : 1.0;
+    const double i11 = rsqrt_nr(p), l21 = q * i11;
+    double s22 = r - l21 * l21;
+    s22 = (s22 > 0.0) ? s22 : 1.0;
+    const double i22 = rsqrt_nr(s22);
+    // W_row = (Z_row - lambda (kappa Z_partner)) iota:  first row of a block {i11, 0, 0}, second {i22, l21, i11}
+    facrow[j * 4 + 0] = i11; facrow[j * 4 + 1] = 0.0; facrow[j * 4 + 2] = 0.0;
+    facrow[j * 4 + 4] = i22; facrow[j * 4 + 5] = l21; facrow[j * 4 + 6] = i11;
+    if (__ballot(bad) != 0ull && lane == 0) atomicAdd(fault, 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lq + 4 * r;
+    const double io = facrow[row * 4], la = facrow[row * 4 + 1], ka = facrow[row * 4 + 2];
+    const double pr = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(Z[r]), 0x401F),
+                                       __builtin_amdgcn_ds_swizzle(__double2loint(Z[r]), 0x401F));   // row ^ 1
+    Wt[lcol * TL_LD + row] = (Z[r] - la * (ka * pr)) * io;
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------
 // Tile Cholesky through memory, for systems too large for the register file (eaqhm_ls_mfma_kernel).
 //
