@@ -20,6 +20,7 @@ namespace eaqhm {
 int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb);  // eaqhm_ls_mfma.hip
 size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax);
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid);              // eaqhm_ls_tile.hip
+int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A);                    // eaqhm_ls_tile.hip (classes, zero counts)
 size_t ls_tile_scratch_stride(int nmax, int Nmax);
 bool ls_tile_applicable(int Kcmax, int Nmax);
 
@@ -233,6 +234,8 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
   B.scratch = (double*)ctx->scratch;
   int min_nb = 0;
+  rc = launch_ls_prepass(ctx, B);
+  if (rc) return rc;
   if (tile_path) {   // small frames: everything in registers/LDS; the rest falls through
     B.scratch_stride = st_t; B.work_counter = counters + 2;
     rc = launch_ls_tile(ctx, B, grid);

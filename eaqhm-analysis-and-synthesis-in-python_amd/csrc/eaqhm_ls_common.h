@@ -207,68 +207,124 @@ __device__ inline void toeplitz_entry(const double* tab, int TB, double ssq, int
                 n, re, im);
 }
 
-// Phase A1 (adaptation >= 1): one thread per active slot windows its track, bridges zero gaps
-// (functions.py:251-278: interior gaps linearly, edge gaps held; positions decided on fm, applied to fm and
-// am), forms the running sums of fm relative to the window middle and the amplitude ratios
-// (functions.py:508-518), and leaves exp(j*2*pi*fm[mid]/fs) in rho.
-// Q is (N+1) x n: row u+1 <-> sample u, row 0 = the virtual sample u = -1;  r is N x n.
-__device__ inline void fill_columns(const LsArgs& A, double* Q, double* r, double* rho, const int* mycols, int n, int N,
-                                    int mid, int c, int wl, bool seeds) {
+// logical column cc of the chunk rows of sample pair el lives at XCOL(cc, el): the 16 lanes that write one column of 16
+// different pairs hit 16 different LDS banks, and the MFMA operand reads (column (lcol + row / 2) & 15) stay conflict-free
+#define XCOL(cc, el) (((cc) & ~15) | (((cc) + (el)) & 15))
+
+// ---- Phase A1 -----------------------------------------------------------------------------------------------
+// Per-slot set-up.  A slot whose track has no zero inside the frame's window (two look-ups in the zero counts;
+// the common case) needs nothing but its centre values: the basis build reads the track itself and integrates
+// the frequency on the fly, outwards from the centre.  A slot with gaps gets its window bridged
+// (functions.py:251-278) into the workgroup's scratch rows, which the build then reads instead of the track.
+//   ci[j]: [0] running sum of fm over (mid, mid+d], [1] over [mid-d, mid]  (carried from chunk to chunk),
+//          [2] / [3] pointers to the slot's fm / am window (track or bridged copy),
+//          [STRIDE-3] 1/(am_mid+eps), [STRIDE-2..STRIDE-1] rho = exp(j 2 pi fm_mid / fs)      (functions.py:508-518, :284-285)
+// masks: [n][nchs] nonzero masks of the 64-sample chunks of the slots with gaps, gappy: [n] flags (work space).
+template <int STRIDE, int NWAVES>
+__device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, int Npad, double* ci,
+                                     unsigned long long* masks, int* gappy, const int* mycols, int n, int N, int mid,
+                                     int c, int wl, bool seeds, int lane, int wave, int nchs) {
   const double eps = 10e-5;  // functions.py:517
+  const int nch = (N + 63) >> 6;
+  const long long t0 = (long long)c - wl;
+  // the argument block is read through a per-lane pointer: fetch what this function uses once, into scalars
+  const unsigned short* zloc = uni(A.zloc);
+  const int* ztot = uni(A.ztot);
+  const double* fm_all = uni(A.fm_cur);
+  const double* am_all = uni(A.am_cur);
+  const long long L = ((long long)uni((int)(A.L >> 32)) << 32) | (unsigned)uni((int)(A.L & 0xffffffffll));
+  const int zchunks = uni(A.zchunks);
+  const double w1 = uni(2.0 * M_PI / A.fs);
+  auto centre = [&](int j, double fv, double av) {
+    ci[j * STRIDE + STRIDE - 3] = 1.0 / (av + eps);
+    double sn, cs;
+    sincos_cw(fv * w1, &sn, &cs);
+    ci[j * STRIDE + STRIDE - 2] = cs;
+    ci[j * STRIDE + STRIDE - 1] = sn;
+  };
+  int anyg = 0;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    // zeros of the track inside [c-wl, c+wl] from the chunked zero counts;
+    // a seeded slot 0 (functions.py:209-210) shows substituted values: route it through the bridged copy too
     const int k = mycols[j];
-    const long long t0 = (long long)c - wl;
-    double* Qc = Q + j;  // sample u at Qc[(u+1)*n]
-    double* rc = r + j;  // sample u at rc[u*n]
-    int last = -1;
-    double ylo_f = 0, ylo_a = 0;
-    for (int u = 0; u < N; ++u) {
-      double v = track_fm(A, k, t0 + u, c, seeds);
-      if (v != 0.0) {
-        double va = track_am(A, k, t0 + u, c, seeds);
-        if (last < u - 1) {
-          if (last < 0) {  // leading gap: hold (functions.py:259-263)
-            for (int g = 0; g < u; ++g) { Qc[(size_t)(g + 1) * n] = v; rc[(size_t)g * n] = va; }
-          } else {         // interior gap: linear (functions.py:277-278)
-            double dx = (double)(u - last);
-            double sf = (v - ylo_f) / dx, sa = (va - ylo_a) / dx;
-            for (int g = last + 1; g < u; ++g) {
-              double xx = (double)(g - last);
-              Qc[(size_t)(g + 1) * n] = sf * xx + ylo_f;
-              rc[(size_t)g * n] = sa * xx + ylo_a;
-            }
-          }
-        }
-        Qc[(size_t)(u + 1) * n] = v;
-        rc[(size_t)u * n] = va;
-        last = u; ylo_f = v; ylo_a = va;
+    const long long b = (long long)c + wl, a1 = (long long)c - wl - 1;
+    const int cb = (int)(b >> 10), ca = (a1 >= 0) ? (int)(a1 >> 10) : 0;
+    // (the centre values are requested together with the zero counts: one memory round trip, not two)
+    const double fmc = fm_all[(size_t)k * L + c], amc = am_all[(size_t)k * L + c];
+    int zc = zloc[(size_t)k * L + b];
+    for (int ch = ca; ch < cb; ++ch) zc += ztot[(size_t)k * zchunks + ch];   // (one chunk boundary inside the window, rarely two)
+    if (a1 >= 0) zc -= zloc[(size_t)k * L + a1];
+    const int g = (zc != 0 || (seeds && k == 0)) ? 1 : 0;
+    gappy[j] = g;
+    anyg |= g;
+    ci[j * STRIDE + 0] = 0.0;
+    ci[j * STRIDE + 1] = 0.0;
+    // where the build reads this slot's window from: the bridged copy or the track itself
+    const size_t trk = (size_t)k * L + t0;
+    ((const double**)(ci + j * STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (fm_all + trk);
+    ((const double**)(ci + j * STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (am_all + trk);
+    if (!g) centre(j, fmc, amc);   // (a seeded slot 0 is never gap-free)
+  }
+  if (!__syncthreads_or(anyg)) return;
+  // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
+  for (int it = wave; it < n * nch; it += NWAVES) {
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
+    if (!gappy[j]) continue;
+    const double fv = (t < N) ? track_fm(A, mycols[j], t0 + t, c, seeds) : 0.0;
+    const unsigned long long m = __ballot(fv != 0.0);
+    if (lane == 0) masks[j * nchs + ch] = m;
+  }
+  __syncthreads();
+  for (int it = wave; it < n * nch; it += NWAVES) {
+    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane, k = mycols[j];
+    if (!gappy[j] || t >= N) continue;
+    double fv = track_fm(A, k, t0 + t, c, seeds), av = track_am(A, k, t0 + t, c, seeds);
+    if (fv == 0.0) {  // nearest nonzero samples on both sides (functions.py:251-278)
+      int p = -1, q = -1;
+      {
+        unsigned long long m = masks[j * nchs + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+        int cc = ch;
+        while (m == 0ull && cc > 0) { --cc; m = masks[j * nchs + cc]; }
+        if (m != 0ull) p = (cc << 6) + 63 - __clzll((long long)m);
+      }
+      {
+        unsigned long long m = masks[j * nchs + ch] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
+        int cc = ch;
+        while (m == 0ull && cc < nch - 1) { ++cc; m = masks[j * nchs + cc]; }
+        if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
+      }
+      if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
+        fv = track_fm(A, k, t0 + q, c, seeds); av = track_am(A, k, t0 + q, c, seeds);
+      } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
+        fv = track_fm(A, k, t0 + p, c, seeds); av = track_am(A, k, t0 + p, c, seeds);
+      } else {             // interior gap: linear (functions.py:277-278)
+        const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
+        const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
+        const double dx = (double)(q - p), xx = (double)(t - p);
+        fv = ((f1v - f0v) / dx) * xx + f0v;
+        av = ((a1v - a0v) / dx) * xx + a0v;
       }
     }
-    for (int g = last + 1; g < N; ++g) {  // trailing gap: hold (functions.py:265-271)
-      Qc[(size_t)(g + 1) * n] = ylo_f; rc[(size_t)g * n] = ylo_a;
-    }
-    // running sums relative to the middle: Q[u] = sum_{v<=u} fm[v] - sum_{v<=mid} fm[v]
-    const double fmid = Qc[(size_t)(mid + 1) * n];
-    double acc = 0.0;
-    Qc[(size_t)(mid + 1) * n] = 0.0;
-    for (int u = mid + 1; u < N; ++u) {
-      acc += Qc[(size_t)(u + 1) * n];
-      Qc[(size_t)(u + 1) * n] = acc;
-    }
-    acc = 0.0;
-    double fnext = fmid;
-    for (int u = mid - 1; u >= -1; --u) {
-      double tmp = (u >= 0) ? Qc[(size_t)(u + 1) * n] : 0.0;
-      acc -= fnext;
-      Qc[(size_t)(u + 1) * n] = acc;
-      fnext = tmp;
-    }
-    const double amid = rc[(size_t)mid * n] + eps;
-    for (int u = 0; u < N; ++u) rc[(size_t)u * n] = (eps + rc[(size_t)u * n]) / amid;
-    double sn, cs;
-    sincos_cw((2.0 * M_PI * fmid) / A.fs, &sn, &cs);
-    rho[2 * j] = cs; rho[2 * j + 1] = sn;
+    Qf[(size_t)j * Npad + t] = fv;
+    Af[(size_t)j * Npad + t] = av;
+    if (t == mid) centre(j, fv, av);
   }
+  __syncthreads();
+}
+
+// inclusive sum over each aligned group of 16 lanes (DPP row shifts: a row is 16 lanes, zeros are shifted in)
+template <int CTRL>
+__device__ inline double dpp_row(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double scan16(double x) {
+  x += dpp_row<0x111>(x);  // row_shr:1
+  x += dpp_row<0x112>(x);  // row_shr:2
+  x += dpp_row<0x114>(x);  // row_shr:4
+  x += dpp_row<0x118>(x);  // row_shr:8
+  return x;
 }
 
 // Phase C (round-1 form): left-looking complex Cholesky on transposed storage Lt[k][i] = R[i][k] (coalesced

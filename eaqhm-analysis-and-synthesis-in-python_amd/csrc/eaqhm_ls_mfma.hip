@@ -3,17 +3,19 @@
 // One workgroup of 512 threads (8 waves, 2 per SIMD) owns one frame at a time; frames are pulled from an
 // atomic queue (frames differ in size, so static striding leaves tails).
 //
-//   A1   one thread per active slot: track window, gap fill, running sums, amplitude ratios  -> global
-//        scratch Q, r ([sample][slot], slot fastest: coalesced for the next step)        (eaqhm_ls_common.h)
-//   A3+B time is cut into chunks of 16 sample PAIRS (u, N-2-u): the pair shares its sincos work because the
-//        negative-frequency column at u is the time-reversed positive one (functions.py:284-285).  All
-//        threads build the 32 basis rows of a chunk in LDS (planar re/im, [row][column], row stride
-//        ≡ 16 (mod 32) doubles so that the four 16-lane groups of an MFMA operand read hit disjoint
-//        banks); then every wave runs v_mfma_f64_16x16x4_f64 on its share of the (tile, weight) units:
-//            G_p[I][J] += X_I^H diag(w^2 n^p) X_J,  p = 0,1,2,
-//        4 real MFMAs per k-step (re·re + im·im, re·im - im·re), accumulators stay in registers for the
-//        whole frame.  The signal window is one more basis column, so the right-hand sides are tiles of
-//        the same contraction.
+//   A1   per-slot set-up (prepare_slots, eaqhm_ls_common.h): a slot without a zero inside the window needs only its
+//        centre values, one with gaps gets its window bridged into the workgroup's scratch rows
+//   A3+B time is cut into chunks of up to 16 sample PAIRS (mid-d-1, mid+d) taken from the window centre outwards: the
+//        pair shares its sincos work because the negative-frequency column at u is the time-reversed positive one
+//        (functions.py:284-285), and the phase integral relative to the centre (functions.py:508-515) is a running
+//        sum: the 16 lanes of a slot load their fm / am straight from the [Kmax][L] tracks, a 16-lane DPP scan plus a
+//        per-slot carry gives the phase.  All threads build the basis rows of a chunk in LDS (planar re/im,
+//        [row][column], row stride ≡ 16 (mod 32) doubles and a per-pair rotation of the columns inside each block of
+//        16: transposing writes and MFMA operand reads are both conflict-free); then every wave runs
+//        v_mfma_f64_16x16x4_f64 on its tiles:  G_p[I][J] += X_I^H diag(w^2 n^p) X_J,  p = 0,1,2, three real products
+//        per complex one, operands read once for the three weights.  The accumulators of a pass stay in registers;
+//        a frame takes ceil(tiles / 16) passes over its window.  The signal window is one more basis column, so the
+//        right-hand sides are tiles of the same contraction.
 //   C    system matrix [[G0,G1],[G1,G2]] + RHS row -> scratch, Cholesky + back substitution
 //   D    frequency mismatch, acceptance, record row                                     (eaqhm_ls_common.h)
 #include "eaqhm_ls_common.h"
@@ -23,11 +25,12 @@ namespace eaqhm {
 
 #define MF_THREADS 512
 #define MF_WAVES 8
-#define MF_NSLOT 8   // (tile, weight) units per wave per pass: 64 units = 21 complex tiles -> nb <= 6 in one pass
+#define MF_CI 8      // doubles of per-slot info: carries, window pointers, 1/(am_mid+eps), rho (prepare_slots)
+#define MF_NT 2      // base Gramian tiles per wave and pass, each with its three weights (9 accumulators of 8 VGPRs)
 
 struct MfScratch {
-  double* Q;   // (Nmax+1) * nmax
-  double* r;   // (Nmax+1) * nmax
+  double* Q;   // Npad * nmax   bridged frequency windows
+  double* r;   // Npad * nmax   bridged amplitude windows
   double* T;   // stacked padded system, 16x16 complex tiles (eaqhm_ls_chol.h)
   double* WT;  // inverse diagonal tiles
   double* D0;  // original diagonal of the system (16 per tile row)
@@ -39,7 +42,7 @@ __host__ __device__ inline size_t mf_tile_doubles(int Kcmax) {
 }
 __host__ __device__ inline size_t mf_scratch_doubles(int nmax, int Nmax, int Kcmax) {
   const size_t nt = 2 * (((size_t)Kcmax + 15) / 16) + 1;
-  return 2 * (size_t)(Nmax + 1) * nmax + mf_tile_doubles(Kcmax) + nt * 2 * TL_TILE + nt * 16;
+  return 2 * (size_t)(((Nmax + 63) >> 6) << 6) * nmax + mf_tile_doubles(Kcmax) + nt * 2 * TL_TILE + nt * 16;
 }
 
 __device__ inline void tile_of(int q, int& I, int& J) {
@@ -49,34 +52,32 @@ __device__ inline void tile_of(int q, int& I, int& J) {
   J = q - I * (I + 1) / 2;
 }
 
-extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int TS, int ldx_max, int min_nb) {
+extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int plane, int min_nb) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (min_nb > 0 && A.cls[LS_BIG_CLASS] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
   const int tid = threadIdx.x, nt = MF_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the unit bookkeeping in SGPRs
   const int Mmax = 2 * A.Kcmax;
-  double* Xre = lds;                         // TS * ldx_max
-  double* Xim = Xre + (size_t)TS * ldx_max;  // TS * ldx_max
-  double* Wp = Xim + (size_t)TS * ldx_max;   // 3 * TS   weights w^2 n^p per chunk row
-  double* rho = Wp + 3 * TS;                 // 2 * nmax
-  double* rowj = rho + 2 * A.nmax;           // 2 * Mmax
-  double* xs = rowj + 2 * Mmax;              // 2 * Mmax
+  const int Npad = ((A.Nmax + 63) >> 6) << 6, nchs = Npad >> 6;
+  double* const Xbase = lds;
+  double* Wp = lds + (size_t)2 * plane;          // 3 * 32  weights w^2 n^p per chunk row   (the chunk planes come first)
+  double* ci = Wp + 96;                      // nmax * MF_CI  per-slot info (prepare_slots)
+  double* xs = ci + (size_t)A.nmax * MF_CI;  // 2 * Mmax
   double* sh = xs + 2 * Mmax;                // 16
   int* shi = (int*)(sh + 12);
+  unsigned long long* masks = (unsigned long long*)lds;           // [nmax][nchs]  (over the planes, set-up only)
+  int* gappy = (int*)(masks + (size_t)A.nmax * nchs);             // [nmax]
   MfScratch S;
   {
     double* base = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
-    S.Q = base;
-    S.r = S.Q + (size_t)(A.Nmax + 1) * A.nmax;
-    S.T = S.r + (size_t)(A.Nmax + 1) * A.nmax;
+    S.Q = base;                                  // bridged fm[j][t] of the slots with gaps
+    S.r = S.Q + (size_t)Npad * A.nmax;           // bridged am[j][t]
+    S.T = S.r + (size_t)Npad * A.nmax;
     S.WT = S.T + mf_tile_doubles(A.Kcmax);
     S.D0 = S.WT + (2 * (((size_t)A.Kcmax + 15) / 16) + 1) * 2 * TL_TILE;
   }
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
-  for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // finite everywhere (rows with weight 0)
-  __syncthreads();
-  const int PE = TS / 2;  // sample pairs per chunk
 
   // after eaqhm_ls_tile_kernel (min_nb > 0) only the frames of the last size class are left, usually none
   const int n_items = (min_nb > 0) ? A.cls[LS_BIG_CLASS] : A.n_frames;
@@ -95,20 +96,22 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     const int nbk = (Kc + 15) >> 4, ntl = 2 * nbk + 1;   // stacked padded tile rows (eaqhm_ls_chol.h)
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
-    const int ntiles = nb * (nb + 1) / 2, units = 3 * ntiles;
-    const int npass = (units + MF_WAVES * MF_NSLOT - 1) / (MF_WAVES * MF_NSLOT);
+    const int ntiles = nb * (nb + 1) / 2;
+    const int npass = (ntiles + MF_WAVES * MF_NT - 1) / (MF_WAVES * MF_NT);
     const double f0 = uni((A.mode == 0) ? A.frame_f0[f] : A.f0_stale);
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
-    const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
+    const int npairs = mid + 1;  // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid (u = -1: the virtual sample before the window)
+    // rows per chunk: what the planes hold at this frame's row stride (16 pairs for the usual frame sizes)
+    int TSf = (plane / ldx) & ~7;
+    TSf = (TSf > 32) ? 32 : TSf;
+    const int PE = TSf >> 1;
+    double* Xre = Xbase;
+    double* Xim = Xbase + (size_t)TSf * ldx;
 
-    for (int q = tid; q < 2 * TS * ldx_max; q += nt) Xre[q] = 0.0;  // the factorisation used this region as work space
-    if (A.mode == 1) fill_columns(A, S.Q, S.r, rho, mycols, n, N, mid, c, wl, seeds);
-    // padding columns of this frame must be zero
-    for (int q = tid; q < TS * (C1p - C1); q += nt) {
-      int row = q / (C1p - C1), col = C1 + q - row * (C1p - C1);
-      Xre[row * ldx + col] = 0.0;
-      Xim[row * ldx + col] = 0.0;
-    }
+    if (A.mode == 1)
+      prepare_slots<MF_CI, MF_WAVES>(A, S.Q, S.r, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, nchs);
+    // the factorisation and the slot set-up used the planes as work space: finite everywhere, padding columns zero
+    for (int q = tid; q < 2 * plane; q += nt) Xbase[q] = 0.0;
     // right-hand-side tile row: zero, its diagonal tile the identity (row 0 is filled from the signal row below)
     for (int q = tid; q < ntl * 512; q += nt) {
       const int Qt = q >> 9, e = q & 511;
@@ -120,7 +123,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
       // ---- adaptation 0: the stacked padded system straight from the Toeplitz tables (eaqhm_ls_common.h): no basis,
       //      no contraction passes.  Work space: the chunk planes.
       const int TB = A.Kcmax + 1, NCH = 2;
-      double* tab = Xre;                                   // [TZ_NQ][TB]
+      double* tab = Xbase;                                 // [TZ_NQ][TB]
       double* part = tab + (size_t)TZ_NQ * TB;             // [NCH][TZ_NQ][TB]
       double* W2 = part + (size_t)NCH * TZ_NQ * TB;        // [wl+1] each
       const int wpad = ((A.Nmax >> 1) + 8) & ~7;
@@ -158,111 +161,155 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
       }
     } else
     for (int pass = 0; pass < npass; ++pass) {
-      d4 accR[MF_NSLOT], accI[MF_NSLOT];
-      int tI[MF_NSLOT], tJ[MF_NSLOT], wsel[MF_NSLOT];
-      bool live[MF_NSLOT];
+      // every slot is one 16x16 tile of the base Gramian with all three weights: the operands are read once per k-step
+      // for the three products, and every complex product is three real ones (P1 = re re, P2 = im im,
+      // P3 = (re + im)(im' - re'):  Re = P1 + P2,  Im = P3 + P1 - P2): 9 MFMAs per tile and k-step instead of 12
+      d4 P1[MF_NT][3], P2[MF_NT][3], P3[MF_NT][3];
+      int tI[MF_NT], tJ[MF_NT];
+      bool live[MF_NT];
 #pragma unroll
-      for (int sl = 0; sl < MF_NSLOT; ++sl) {
-        accR[sl] = (d4){0, 0, 0, 0};
-        accI[sl] = (d4){0, 0, 0, 0};
-        const int x = (pass * MF_NSLOT + sl) * MF_WAVES + wave;
-        live[sl] = x < units;
+      for (int sl = 0; sl < MF_NT; ++sl) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          P1[sl][w] = (d4){0, 0, 0, 0};
+          P2[sl][w] = (d4){0, 0, 0, 0};
+          P3[sl][w] = (d4){0, 0, 0, 0};
+        }
+        const int x = (pass * MF_NT + sl) * MF_WAVES + wave;
+        live[sl] = x < ntiles;
         int I = 0, J = 0;
-        tile_of(live[sl] ? x / 3 : 0, I, J);
+        tile_of(live[sl] ? x : 0, I, J);
         tI[sl] = I; tJ[sl] = J;
-        wsel[sl] = live[sl] ? x % 3 : 0;
       }
 
-      for (int e0 = 0; e0 < npairs; e0 += PE) {
-        // ---- build the chunk: rows 2*el (sample u = e-1) and 2*el+1 (sample v = N-1-e)
+      if (pass > 0) {   // the running sums start again at the window centre
+        for (int j = tid; j < n; j += nt) { ci[j * MF_CI] = 0.0; ci[j * MF_CI + 1] = 0.0; }
+        __syncthreads();
+      }
+      const double w1 = 2.0 * M_PI / A.fs;   // phases are q * (2 pi / fs) (<= 2 ulp from (2 pi q) / fs of functions.py:513)
+      for (int d0 = 0; d0 < npairs; d0 += PE) {
+        // ---- build the chunk: rows 2*el (sample u = mid-d-1) and 2*el+1 (sample v = mid+d), d = d0 + el; logical
+        //      column cc of those two rows lives at XCOL(cc, el)
+#ifndef EAQHM_EXPERIMENT_NOBUILD   /* (timing experiment: stale basis rows; wrong results) */
 #pragma clang loop unroll(disable)
-        for (int idx = tid; idx < PE * n; idx += nt) {
-          const int el = idx / n, j = idx - el * n, e = e0 + el;
-          if (e >= npairs) continue;
-          const int u = e - 1, v = N - 1 - e;
-          double su, cu, sv, cv, ru = 1.0, ru1 = 1.0, rv = 1.0, rv1 = 1.0, pr = 1.0, pi = 0.0;
-          if (A.mode == 1) {
-            sincos_cw((2.0 * M_PI * S.Q[(size_t)(u + 1) * n + j]) / A.fs, &su, &cu);
-            sincos_cw((2.0 * M_PI * S.Q[(size_t)(v + 1) * n + j]) / A.fs, &sv, &cv);
-            if (u >= 0) { ru = S.r[(size_t)u * n + j]; rv1 = S.r[(size_t)(v + 1) * n + j]; }
-            ru1 = S.r[(size_t)(u + 1) * n + j];
-            rv = S.r[(size_t)v * n + j];
-            pr = rho[2 * j]; pi = rho[2 * j + 1];
-            // positive column at t uses E1(t); negative column at t uses r[mirror+1] * E1(mirror) * rho
-            double* xr = Xre + (2 * el) * ldx;
-            double* xi = Xim + (2 * el) * ldx;
-            if (u >= 0) {
-              xr[n + 1 + j] = ru * cu;                  xi[n + 1 + j] = ru * su;
-              xr[j] = rv1 * (cv * pr - sv * pi);        xi[j] = rv1 * (cv * pi + sv * pr);
-            }
-            xr += ldx; xi += ldx;
-            xr[n + 1 + j] = rv * cv;                    xi[n + 1 + j] = rv * sv;
-            xr[j] = ru1 * (cu * pr - su * pi);          xi[j] = ru1 * (cu * pi + su * pr);
-          } else {
-            const double fk = (double)(j + 1) * f0;
-            double* xr = Xre + (2 * el) * ldx;
-            double* xi = Xim + (2 * el) * ldx;
-            if (u >= 0) {
-              sincos_cw(((double)(u - mid) * 2.0 * M_PI * fk) / A.fs, &su, &cu);
-              xr[n + 1 + j] = cu; xi[n + 1 + j] = su; xr[j] = cu; xi[j] = -su;
-            }
-            sincos_cw(((double)(v - mid) * 2.0 * M_PI * fk) / A.fs, &sv, &cv);
-            xr += ldx; xi += ldx;
-            xr[n + 1 + j] = cv; xi[n + 1 + j] = sv; xr[j] = cv; xi[j] = -sv;
+        for (int idx = tid; idx < 16 * n; idx += nt) {
+          const int el = idx & 15, j = idx >> 4, d = d0 + el;
+          const bool act = (el < PE) && (d <= mid);
+          const int u = mid - d - 1;
+          double* cj = ci + j * MF_CI;
+          const double* fb = ((const double**)cj)[2];   // bridged copy or the track itself (prepare_slots)
+          const double* ab = ((const double**)cj)[3];
+          // every load of the item up front, indices clamped into the window (results of clamped ones unused)
+          const int dc = act ? d : mid;
+          const double fu1 = fb[mid - dc], fv = fb[mid + dc];
+          const double au = ab[(mid - dc - 1 >= 0) ? (mid - dc - 1) : 0], au1 = ab[mid - dc];
+          const double av = ab[mid + dc], av1 = ab[(mid + dc + 1 < N) ? (mid + dc + 1) : (N - 1)];
+          __builtin_amdgcn_sched_barrier(0);   // all six requests in flight before anything waits on one
+          // F(v) - F(mid) = sum of fm over (mid, v];  F(u) - F(mid) = -sum over [u+1, mid]
+          const double xu = act ? fu1 : 0.0, xv = (act && d >= 1) ? fv : 0.0;
+          const double qv = cj[0] + scan16(xv), qu = -(cj[1] + scan16(xu));
+          if (el == 15) { cj[0] = qv; cj[1] = -qu; }   // carried to the next chunk (read again after two barriers)
+          if (!act) continue;
+          const double ainv = cj[MF_CI - 3], pr = cj[MF_CI - 2], pi = cj[MF_CI - 1];
+          double su, cu, sv, cv;
+          sincos_cw(qu * w1, &su, &cu);
+          sincos_cw(qv * w1, &sv, &cv);
+          const double eps = 10e-5;
+          double* xr = Xre + (2 * el) * ldx;
+          double* xi = Xim + (2 * el) * ldx;
+          const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);
+          // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
+          if (u >= 0) {
+            const double ru = (eps + au) * ainv, rv1 = (eps + av1) * ainv;
+            xr[cpos] = ru * cu;                    xi[cpos] = ru * su;
+            xr[cneg] = rv1 * (cv * pr - sv * pi);  xi[cneg] = rv1 * (cv * pi + sv * pr);
           }
+          const double rv = (eps + av) * ainv, ru1 = (eps + au1) * ainv;
+          xr += ldx; xi += ldx;
+          xr[cpos] = rv * cv;                      xi[cpos] = rv * sv;
+          xr[cneg] = ru1 * (cu * pr - su * pi);    xi[cneg] = ru1 * (cu * pi + su * pr);
         }
-#pragma clang loop unroll(disable)
-        for (int row = tid; row < TS; row += nt) {
-          const int e = e0 + (row >> 1);
-          const int t = (row & 1) ? (N - 1 - e) : (e - 1);
+#endif
+        if (tid < TSf) {   // weights, DC and signal columns: one thread per chunk row
+          const int row = tid, el = row >> 1, d = d0 + el;
+          const int t = (row & 1) ? (mid + d) : (mid - d - 1);
           double w0 = 0.0, sv = 0.0;
-          if (e < npairs && t >= 0) {
-            double w = window_value(A.mode == 0, t, N);
+          if (d <= mid && t >= 0) {
+            const double w = window_value(false, t, N);
             w0 = w * w;
             sv = A.s[(size_t)(c - wl) + t];
           }
           const double nn = (double)(t - mid);
-          Wp[row] = w0; Wp[TS + row] = w0 * nn; Wp[2 * TS + row] = w0 * nn * nn;
-          Xre[row * ldx + n] = 1.0;  Xim[row * ldx + n] = 0.0;   // DC column
-          Xre[row * ldx + Kc] = sv;  Xim[row * ldx + Kc] = 0.0;  // signal column
+          Wp[row] = w0; Wp[32 + row] = w0 * nn; Wp[64 + row] = w0 * nn * nn;
+          Xre[row * ldx + XCOL(n, el)] = 1.0;  Xim[row * ldx + XCOL(n, el)] = 0.0;   // DC column
+          Xre[row * ldx + XCOL(Kc, el)] = sv;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
         }
         __syncthreads();
-        // ---- contraction of the chunk
-        const int lbase = (lane >> 4) * ldx + (lane & 15);
+        // Touch the track lines the NEXT chunk's build will read (per slot four runs of fm and four of am), issued now
+        // and consumed after the contraction: the build then finds its values in L1/L2 instead of waiting a DRAM round
+        // trip per chunk with the matrix pipe idle.
+        double pf = 0.0;
+        {
+          const int d1 = d0 + PE, q = tid & 7;
+          if (d1 <= mid)
+            for (int jp = tid >> 3; jp < n; jp += nt >> 3) {
+              const double* base = ((const double**)(ci + jp * MF_CI))[2 + (q >> 2)];   // fm runs, then am runs
+              const int ext = 15 + (q >> 2);
+              int off = ((q & 3) == 0) ? (mid - d1 - ext) : ((q & 3) == 1) ? (mid - d1) : ((q & 3) == 2) ? (mid + d1) : (mid + d1 + ext);
+              off = (off < 0) ? 0 : (off > N - 1) ? (N - 1) : off;
+              pf += base[off];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- contraction of the chunk (only the k-steps that hold samples: the rest of the last chunk has weight 0)
+        const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;
+        const int ksn = (pcs + 1) >> 1;
+        const int lq = lane >> 4, lcol = lane & 15;
+        const double* wrow = Wp + lq;
+#ifndef EAQHM_EXPERIMENT_NOCONTRACT   /* (timing experiment: no matrix products; wrong results) */
 #pragma unroll
-        for (int sl = 0; sl < MF_NSLOT; ++sl) {
+        for (int sl = 0; sl < MF_NT; ++sl) {
           if (!live[sl]) continue;
-          const double* wrow = Wp + wsel[sl] * TS + (lane >> 4);
-          const double* pAr = Xre + lbase + 16 * tI[sl];
-          const double* pAi = Xim + lbase + 16 * tI[sl];
-          const double* pBr = Xre + lbase + 16 * tJ[sl];
-          const double* pBi = Xim + lbase + 16 * tJ[sl];
+          const int ca = 16 * tI[sl], cb = 16 * tJ[sl];
+          const int sw0 = lcol + (lq >> 1);
+          int rb = lq * ldx;
+          // (requesting the operands of k-step ks+1 ahead of the MFMAs of k-step ks, as the tile kernel does, is slower
+          //  here: 663 vs 630 ms per launch on 12 s of the 48 kHz workload — nine independent MFMAs per k-step and the
+          //  second wave of the SIMD already cover the LDS latency)
 #pragma clang loop unroll(disable)
-          for (int ks = 0; ks < TS / 4; ++ks) {
-            const int ro = 4 * ks * ldx;
-            const double aR = pAr[ro], aI = pAi[ro];
-            const double w = wrow[4 * ks];
-            const double bR = w * pBr[ro], bI = w * pBi[ro];
-            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bR, accR[sl], 0, 0, 0);
-            accR[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bI, accR[sl], 0, 0, 0);
-            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bI, accI[sl], 0, 0, 0);
-            accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, bR, accI[sl], 0, 0, 0);
+          for (int ks = 0; ks < ksn; ++ks) {   // row = 4 ks + lq, column rotation (lcol + row / 2) & 15
+            const int sw = (sw0 + 2 * ks) & 15;
+            const double aR = Xre[rb + ca + sw], aI = Xim[rb + ca + sw], bR = Xre[rb + cb + sw], bI = Xim[rb + cb + sw];
+            rb += 4 * ldx;
+            const double sA = aR + aI;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              const double wv = wrow[w * 32 + 4 * ks];
+              const double bRw = wv * bR, bIw = wv * bI;
+              P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bRw, P1[sl][w], 0, 0, 0);
+              P2[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bIw, P2[sl][w], 0, 0, 0);
+              P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA, bIw - bRw, P3[sl][w], 0, 0, 0);
+            }
           }
         }
+#endif
+        asm volatile("" ::"v"(pf));   // (the touched values themselves are not used)
         __syncthreads();
       }
 
       // ---- accumulators -> tiles of the stacked padded system [[G0,G1^H],[G1,G2]] + RHS row (eaqhm_ls_chol.h).
       // Base tiles are aligned with the stacked ones; positions beyond Kc inside a block are identity padding.
 #pragma unroll
-      for (int sl = 0; sl < MF_NSLOT; ++sl) {
+      for (int sl = 0; sl < MF_NT; ++sl) {
         if (!live[sl]) continue;
-        const int I = tI[sl], J = tJ[sl], p = wsel[sl];
+        const int I = tI[sl], J = tJ[sl];
         const int bl = lane & 15, b = 16 * J + bl;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int al = (lane >> 4) + 4 * rr, a = 16 * I + al;
-          const double gr = accR[sl][rr], gi = accI[sl][rr];
+          const double gr = P1[sl][p][rr] + P2[sl][p][rr], gi = P3[sl][p][rr] + (P1[sl][p][rr] - P2[sl][p][rr]);
           if (a == Kc) {   // signal row: conj(rhs) into row 0 of the RHS tile row, its energy on the diagonal
             if (b < Kc && p == 0) { double* t = S.T + tile_off(ntl - 1, J) + bl; t[0] = gr; t[256] = gi; }
             if (b < Kc && p == 1) { double* t = S.T + tile_off(ntl - 1, nbk + J) + bl; t[0] = gr; t[256] = gi; }
@@ -286,12 +333,13 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
             }
           }
         }
+        }
       }
     }
     __syncthreads();
 
 #ifndef EAQHM_EXPERIMENT_NOCHOL   /* (timing experiment: the frame without its factorisation; wrong results) */
-    tile_cholesky_memory(S.T, S.WT, S.D0, ntl, Kc, nbk, Xre, xs, A.fault);
+    tile_cholesky_memory(S.T, S.WT, S.D0, ntl, Kc, nbk, Xbase, xs, A.fault);
 #endif
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
   }
@@ -301,28 +349,31 @@ size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax) {
   return (mf_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.work_counter are set by the caller (eaqhm_ls_batch)
+// A.scratch / A.scratch_stride / A.work_counter / A.zloc / A.ztot are set by the caller (eaqhm_ls_batch), which has
+// also run the zero-count pass (launch_ls_prepass) for adaptations >= 1
 int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   const int nmax = A.nmax, Kcmax = A.Kcmax;
   const int nbmax = (Kcmax + 1 + 15) / 16;
-  int ldx_max = 16 * nbmax + 16;
-  if (ldx_max * 64 < CH_LDS_DOUBLES) ldx_max = (CH_LDS_DOUBLES / 64 + 15) & ~15;   // the factorisation reuses the chunk planes
-  // ... and so does the closed-form Gramian of adaptation 0 (tables, partial sums, window, signal)
+  const int ldx_max = 16 * nbmax + 16;
+  const int Npad = ((A.Nmax + 63) >> 6) << 6;
+  // everything but the two chunk planes: weights, per-slot info, solution vector, small shared values
+  const size_t fixed = (size_t)(96 + MF_CI * nmax + 4 * Kcmax + 16) * sizeof(double);
+  if (fixed + (size_t)2 * 8 * ldx_max * sizeof(double) > 159 * 1024)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
+  // doubles per chunk plane: as many basis rows per chunk as the LDS holds (up to 32; fewer, longer chunks amortise the
+  // barriers); the planes double as work space of the slot set-up, the closed-form Gramian and the factorisation
+  const int plane = (int)(((159 * 1024 - fixed) / (2 * sizeof(double))) & ~(size_t)15);
+  const size_t lds_bytes = (size_t)2 * plane * sizeof(double) + fixed;
   const size_t tz_doubles = (size_t)3 * TZ_NQ * (Kcmax + 1) + 3 * (((A.Nmax >> 1) + 8) & ~7) + 2 * ((A.Nmax + 7) & ~7);
-  const size_t fixed = (size_t)(2 * nmax + 4 * (2 * Kcmax) + 16) * sizeof(double);
-  // rows per chunk: as many as the LDS holds (multiples of 8 = two k-steps; fewer, longer chunks amortise the
-  // barriers and the partly filled last round of the basis build)
-  int TS = 32;
-  while (TS > 8 && (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed > 158 * 1024) TS -= 8;
-  const size_t lds_bytes = (size_t)(2 * TS * ldx_max + 3 * TS) * sizeof(double) + fixed;
-  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: problem too large for the MFMA variant");
-  if ((size_t)2 * TS * ldx_max < tz_doubles)
+  if ((size_t)2 * plane < tz_doubles)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the closed-form Gramian's work space");
-  if ((size_t)2 * TS * ldx_max < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > CH_NTMAX)
+  if ((size_t)2 * plane < CH_LDS_DOUBLES || 2 * ((Kcmax + 15) / 16) + 1 > CH_NTMAX)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the tile factorisation's work space");
+  if ((size_t)2 * plane * sizeof(double) < (size_t)nmax * (Npad >> 6) * 8 + (size_t)nmax * 4)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the slot set-up's work space");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
-  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max, min_nb);
+  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, plane, min_nb);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

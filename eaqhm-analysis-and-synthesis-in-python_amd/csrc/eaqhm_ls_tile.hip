@@ -40,7 +40,6 @@ namespace eaqhm {
 #define TL_NTMAX 13
 #define CI_STRIDE 20    // per-slot info: 16 chunk carries, qmid, 1/(am_mid+eps), rho.re, rho.im
 #define CI_NCH 16
-#define XCOL(cc, el) (((cc) & ~15) | (((cc) + (el)) & 15))
 
 __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   P = (int)((sqrtf(8.0f * (float)x + 1.0f) - 1.0f) * 0.5f);
@@ -48,119 +47,6 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   while (P * (P + 1) / 2 > x) --P;
   Q = x - P * (P + 1) / 2;
 }
-// ---- Phase A1 -----------------------------------------------------------------------------------------------
-// Per-slot set-up.  A slot whose track has no zero inside the frame's window (two look-ups in the zero counts;
-// the common case) needs nothing but its centre values: the basis build reads the track itself and integrates
-// the frequency on the fly, outwards from the centre.  A slot with gaps gets its window bridged
-// (functions.py:251-278) into the workgroup's scratch rows, which the build then reads instead of the track.
-//   ci[j]: [0] running sum of fm over (mid, mid+d], [1] over [mid-d, mid]  (carried from chunk to chunk),
-//          [2] / [3] pointers to the slot's fm / am window (track or bridged copy),
-//          [17] 1/(am_mid+eps), [18..19] rho = exp(j 2 pi fm_mid / fs)      (functions.py:508-518, :284-285)
-__device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, int Npad, double* ci,
-                                     unsigned long long* masks, int* gappy, const int* mycols, int n, int N, int mid,
-                                     int c, int wl, bool seeds, int lane, int wave, int f) {
-  const double eps = 10e-5;  // functions.py:517
-  const int nch = (N + 63) >> 6;
-  const long long t0 = (long long)c - wl;
-  // the argument block is read through a per-lane pointer: fetch what this function uses once, into scalars
-  const unsigned short* zloc = uni(A.zloc);
-  const int* ztot = uni(A.ztot);
-  const double* fm_all = uni(A.fm_cur);
-  const double* am_all = uni(A.am_cur);
-  const long long L = ((long long)uni((int)(A.L >> 32)) << 32) | (unsigned)uni((int)(A.L & 0xffffffffll));
-  const int zchunks = uni(A.zchunks);
-  const double w1 = uni(2.0 * M_PI / A.fs);
-  auto centre = [&](int j, double fv, double av) {
-    ci[j * CI_STRIDE + 17] = 1.0 / (av + eps);
-    double sn, cs;
-    sincos_cw(fv * w1, &sn, &cs);
-    ci[j * CI_STRIDE + 18] = cs;
-    ci[j * CI_STRIDE + 19] = sn;
-  };
-  int anyg = 0;
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    // zeros of the track inside [c-wl, c+wl] (the window is shorter than a chunk: at most two chunks involved);
-    // a seeded slot 0 (functions.py:209-210) shows substituted values: route it through the bridged copy too
-    const int k = mycols[j];
-    const long long b = (long long)c + wl, a1 = (long long)c - wl - 1;
-    const int cb = (int)(b >> 10), ca = (a1 >= 0) ? (int)(a1 >> 10) : 0;
-    // (the centre values are requested together with the zero counts: one memory round trip, not two)
-    const double fmc = fm_all[(size_t)k * L + c], amc = am_all[(size_t)k * L + c];
-    int zc = zloc[(size_t)k * L + b] + ((cb != ca) ? ztot[(size_t)k * zchunks + ca] : 0);
-    if (a1 >= 0) zc -= zloc[(size_t)k * L + a1];
-    const int g = (zc != 0 || (seeds && k == 0)) ? 1 : 0;
-    gappy[j] = g;
-    anyg |= g;
-    ci[j * CI_STRIDE + 0] = 0.0;
-    ci[j * CI_STRIDE + 1] = 0.0;
-    // where the build reads this slot's window from: the bridged copy or the track itself
-    const size_t trk = (size_t)k * L + t0;
-    ((const double**)(ci + j * CI_STRIDE))[2] = g ? (Qf + (size_t)j * Npad) : (fm_all + trk);
-    ((const double**)(ci + j * CI_STRIDE))[3] = g ? (Af + (size_t)j * Npad) : (am_all + trk);
-    if (!g) centre(j, fmc, amc);   // (a seeded slot 0 is never gap-free)
-  }
-  if (!__syncthreads_or(anyg)) return;
-  // slots with gaps: nonzero masks of every 64-sample chunk first, then the bridged window
-  for (int it = wave; it < n * nch; it += TL_WAVES) {
-    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane;
-    if (!gappy[j]) continue;
-    const double fv = (t < N) ? track_fm(A, mycols[j], t0 + t, c, seeds) : 0.0;
-    const unsigned long long m = __ballot(fv != 0.0);
-    if (lane == 0) masks[j * CI_NCH + ch] = m;
-  }
-  __syncthreads();
-  for (int it = wave; it < n * nch; it += TL_WAVES) {
-    const int j = it / nch, ch = it - j * nch, t = (ch << 6) + lane, k = mycols[j];
-    if (!gappy[j] || t >= N) continue;
-    double fv = track_fm(A, k, t0 + t, c, seeds), av = track_am(A, k, t0 + t, c, seeds);
-    if (fv == 0.0) {  // nearest nonzero samples on both sides (functions.py:251-278)
-      int p = -1, q = -1;
-      {
-        unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
-        int cc = ch;
-        while (m == 0ull && cc > 0) { --cc; m = masks[j * CI_NCH + cc]; }
-        if (m != 0ull) p = (cc << 6) + 63 - __clzll((long long)m);
-      }
-      {
-        unsigned long long m = masks[j * CI_NCH + ch] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
-        int cc = ch;
-        while (m == 0ull && cc < nch - 1) { ++cc; m = masks[j * CI_NCH + cc]; }
-        if (m != 0ull) q = (cc << 6) + __ffsll((long long)m) - 1;
-      }
-      if (p < 0) {         // leading gap: hold the first nonzero (functions.py:259-263)
-        fv = track_fm(A, k, t0 + q, c, seeds); av = track_am(A, k, t0 + q, c, seeds);
-      } else if (q < 0) {  // trailing gap: hold the last nonzero (functions.py:265-271)
-        fv = track_fm(A, k, t0 + p, c, seeds); av = track_am(A, k, t0 + p, c, seeds);
-      } else {             // interior gap: linear (functions.py:277-278)
-        const double f0v = track_fm(A, k, t0 + p, c, seeds), f1v = track_fm(A, k, t0 + q, c, seeds);
-        const double a0v = track_am(A, k, t0 + p, c, seeds), a1v = track_am(A, k, t0 + q, c, seeds);
-        const double dx = (double)(q - p), xx = (double)(t - p);
-        fv = ((f1v - f0v) / dx) * xx + f0v;
-        av = ((a1v - a0v) / dx) * xx + a0v;
-      }
-    }
-    Qf[(size_t)j * Npad + t] = fv;
-    Af[(size_t)j * Npad + t] = av;
-    if (t == mid) centre(j, fv, av);
-  }
-  __syncthreads();
-}
-
-// inclusive sum over each aligned group of 16 lanes (DPP row shifts: a row is 16 lanes, zeros are shifted in)
-template <int CTRL>
-__device__ inline double dpp_row(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline double scan16(double x) {
-  x += dpp_row<0x111>(x);  // row_shr:1
-  x += dpp_row<0x112>(x);  // row_shr:2
-  x += dpp_row<0x114>(x);  // row_shr:4
-  x += dpp_row<0x118>(x);  // row_shr:8
-  return x;
-}
-
 // (adaptation 0: the Gramian in closed form — toeplitz_tables / toeplitz_entry in eaqhm_ls_common.h)
 #define TZ_TB 104     // table stride: m = 0 .. 2 n <= 102
 #define TZ_NCH 8      // chunks of the t range (deterministic two-level summation)
@@ -242,7 +128,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     }
     __syncthreads();
     int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
-    if (mode == 1) prepare_slots(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, f);
+    if (mode == 1) prepare_slots<CI_STRIDE, TL_WAVES>(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, CI_NCH);
     STAMP(0);
 
     // system tiles of this wave
@@ -993,14 +879,9 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
   return (2 * Npad * nmax + 15) & ~(size_t)15;
 }
 
-// A.scratch / A.scratch_stride / A.zloc / A.ztot / A.cls (zeroed header) / A.debug are set by the caller (eaqhm_ls_batch).
-// Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
-int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
-  const int Kcmax = A.Kcmax;
-  const int ldx_max = 16 * TL_NTMAX + 16;
-  const int TS = 32;
-  const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
-  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+// Frames into their size classes, and (adaptations >= 1) the zero counts of the tracks that the slot set-up of both
+// batched kernels looks up.  A.cls (zeroed header) / A.zflag (zeroed) / A.zloc / A.ztot are set by the caller.
+int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A) {
   hipLaunchKernelGGL(eaqhm_ls_classify_kernel, dim3((A.n_frames + 255) / 256), dim3(256), 0, ctx->stream, A);
   HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
@@ -1008,6 +889,17 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
                        A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
     HIP_TRY(ctx, hipGetLastError());
   }
+  return EAQHM_OK;
+}
+
+// A.scratch / A.scratch_stride / A.zloc / A.ztot / A.cls / A.debug are set by the caller (eaqhm_ls_batch), after launch_ls_prepass.
+// Returns the largest number of tile rows handled (frames with more are left to the caller's fallback).
+int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
+  const int Kcmax = A.Kcmax;
+  const int ldx_max = 16 * TL_NTMAX + 16;
+  const int TS = 32;
+  const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
+  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(eaqhm_ls_tile_kernel, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max);
   HIP_TRY(ctx, hipGetLastError());
