@@ -20,11 +20,14 @@
 //   D    frequency mismatch, acceptance, record row                                     (eaqhm_ls_common.h)
 #include "eaqhm_ls_common.h"
 #include "eaqhm_ls_chol.h"
+#include "eaqhm_ls_a0.h"
 
 namespace eaqhm {
 
 #define MF_THREADS 512
 #define MF_WAVES 8
+#define MF_A0_M 19   // adaptation 0 on chip: real systems of up to 19 tile rows (Kc + 1 <= 304)
+#define MF_A0_NCH 4
 #define MF_CI 8      // doubles of per-slot info: carries, window pointers, 1/(am_mid+eps), rho (prepare_slots)
 #define MF_NT 2      // base Gramian tiles per wave and pass, each with its three weights (9 accumulators of 8 VGPRs)
 
@@ -52,7 +55,7 @@ __device__ inline void tile_of(int q, int& I, int& J) {
   J = q - I * (I + 1) / 2;
 }
 
-extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int plane, int min_nb) {
+extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int plane, int min_nb, int a0_onchip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (min_nb > 0 && A.cls[LS_BIG_CLASS] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
   const int tid = threadIdx.x, nt = MF_THREADS;
@@ -89,6 +92,8 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     if (item >= n_items) break;
     // (wave-uniform, but out of LDS / memory: scalar registers for everything derived from them)
     const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)LS_BIG_CLASS * A.n_frames + item] : item);
+    // (adaptation 0: frames of up to MF_A0_M real tile rows were solved on chip by eaqhm_ls_a0big_kernel)
+    if (A.mode == 0 && a0_onchip && ((2 * uni(A.frame_K[f]) + 2 + 15) >> 4) <= MF_A0_M) continue;
     const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
     const int N = 2 * wl + 1, mid = wl;
     const int n = uni((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
@@ -345,6 +350,31 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
   }
 }
 
+// Adaptation 0 of the large frames: two real systems of order Kc + 1 per frame, factorised in the register file
+// (eaqhm_ls_a0.h); three register budgets by the number of tile rows (12 / 17 / 24 tiles per wave on eight waves).  A
+// kernel of its own: called from eaqhm_ls_mfma_kernel the three instantiations cost that kernel's other paths their
+// register allocation (adaptation >= 1 launches 630 -> 741 ms).  Frames beyond MF_A0_M tile rows are left to
+// eaqhm_ls_mfma_kernel (complex system through memory).
+extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_a0big_kernel(LsArgs A, int min_nb, int* cursor) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int nxt;
+  if (min_nb > 0 && A.cls[LS_BIG_CLASS] == 0) return;
+  const int n_items = (min_nb > 0) ? A.cls[LS_BIG_CLASS] : A.n_frames;
+  const int TB = A.Kcmax + 1, WP = ((A.Nmax >> 1) + 8) & ~7, NP = (A.Nmax + 7) & ~7;
+  for (;;) {
+    if (threadIdx.x == 0) nxt = atomicAdd(cursor, 1);
+    __syncthreads();
+    const int item = uni(nxt);
+    __syncthreads();
+    if (item >= n_items) break;
+    const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)LS_BIG_CLASS * A.n_frames + item] : item);
+    const int m0 = (2 * uni(A.frame_K[f]) + 2 + 15) >> 4;
+    if (m0 <= 13) a0_frame<12, MF_A0_M, 1>(A, lds, f, TB, MF_A0_NCH, WP, NP);
+    else if (m0 <= 16) a0_frame<17, MF_A0_M, 1>(A, lds, f, TB, MF_A0_NCH, WP, NP);
+    else if (m0 <= MF_A0_M) a0_frame<24, MF_A0_M, 1>(A, lds, f, TB, MF_A0_NCH, WP, NP);
+  }
+}
+
 size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax) {
   return (mf_scratch_doubles(nmax, Nmax, Kcmax) + 15) & ~(size_t)15;
 }
@@ -373,7 +403,16 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: frame size outside the slot set-up's work space");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
-  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, plane, min_nb);
+  const size_t a0_bytes = a0_lds_doubles(MF_A0_M, 1, Kcmax + 1, MF_A0_NCH, ((A.Nmax >> 1) + 8) & ~7, (A.Nmax + 7) & ~7, Kcmax) * sizeof(double);
+  const int a0_onchip = (A.mode == 0 && a0_bytes <= 160 * 1024) ? 1 : 0;
+  if (a0_onchip) {
+    // its frame cursor: a free slot of the class header / of the zeroed counter block (eaqhm_ls_batch)
+    int* cursor = (min_nb > 0) ? (A.cls + 15) : (A.work_counter + 2);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_a0big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a0_bytes));
+    hipLaunchKernelGGL(eaqhm_ls_a0big_kernel, dim3(grid), dim3(MF_THREADS), a0_bytes, ctx->stream, A, min_nb, cursor);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, plane, min_nb, a0_onchip);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }

@@ -30,6 +30,7 @@
 // eaqhm_ls_mfma_kernel (same Gramian, factorisation through scratch memory).
 #include "eaqhm_ls_common.h"
 #include "eaqhm_ls_chol.h"
+#include "eaqhm_ls_a0.h"
 
 namespace eaqhm {
 
@@ -40,6 +41,8 @@ namespace eaqhm {
 #define TL_NTMAX 13
 #define CI_STRIDE 20    // per-slot info: 16 chunk carries, qmid, 1/(am_mid+eps), rho.re, rho.im
 #define CI_NCH 16
+#define A0_NS 7        // adaptation 0: tiles per wave of a real system of <= 7 tile rows (order Kc + 1 <= 104) on 4 waves
+#define A0_M 7
 
 __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   P = (int)((sqrtf(8.0f * (float)x + 1.0f) - 1.0f) * 0.5f);
@@ -554,237 +557,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   }
 }
 
-// ---- adaptation 0 as TWO REAL systems -------------------------------------------------------------------------
-// At adaptation 0 the signal is real, the columns come in conjugate pairs and the window is symmetric, so the
-// solution has a_{-k} = conj(a_k), b_{-k} = conj(b_k), and in the real basis
-//     even:  cos(k theta n) (k = 0..K),  n sin(k theta n) (k = 1..K)        odd:  sin(k theta n) (k = 1..K),  n cos(k theta n) (k = 0..K)
-// the weighted normal equations fall apart into two REAL symmetric systems of order Kc = 2K+1 (even functions against
-// odd ones sum to zero under the symmetric weight).  Their entries come from the same Toeplitz tables
-// (cos a cos b = (cos(a-b) + cos(a+b))/2 etc.), and
-//     a_0 = u_0,  a_k = (u_k - j v_k)/2,   b_0 = p_0,  b_k = (p_k - j q_k)/2      (u: cos, q: n sin | v: sin, p: n cos).
-// Half the order means half the chain of dependent diagonal steps, a quarter of the tiles, real arithmetic (one MFMA
-// where the complex code needs three), and the two systems are factorised side by side: waves 0-3 take the even one,
-// waves 4-7 the odd one, each with its own two-wave diagonal pipeline (diag_Dr / diag_Zr), sharing the barriers.
-#define A0_NS 7        // tiles per wave: a system has <= 28 tiles (7 tile rows: order Kc + 1 <= 104) on 4 waves
-#define A0_M 7
-// entry (gi, gj) of system `sys` (0 even, 1 odd), order Kc + 1 with the right-hand side as row / column Kc
-__device__ inline double a0_entry(const double* tab, double ssq, int sys, int gi, int gj, int K, int Kc) {
-  if (gi > Kc || gj > Kc) return (gi == gj) ? 1.0 : 0.0;      // identity padding behind the right-hand side
-  if (gi == Kc && gj == Kc) return ssq;
-  const double* c0 = tab; const double* s1 = tab + TZ_TB; const double* c2 = tab + 2 * TZ_TB;
-  if (gi == Kc || gj == Kc) {                                  // sum w^2 s f(n)
-    const int e = (gi == Kc) ? gj : gi;
-    if (sys == 0) return (e <= K) ? tab[3 * TZ_TB + e] : tab[6 * TZ_TB + (e - K)];        // Re r0[k] | Im r1[k]
-    return (e < K) ? tab[4 * TZ_TB + (e + 1)] : tab[5 * TZ_TB + (e - K)];                 // Im r0[k] | Re r1[k]
-  }
-  // type 0: plain function (cos / sin), type 1: n times the other one (n sin / n cos); harmonic numbers k, l
-  const int split = (sys == 0) ? K + 1 : K;
-  const int ti = (gi >= split) ? 1 : 0, tj = (gj >= split) ? 1 : 0;
-  const int k = (sys == 0) ? (ti ? gi - K : gi) : (ti ? gi - K : gi + 1);
-  const int l = (sys == 0) ? (tj ? gj - K : gj) : (tj ? gj - K : gj + 1);
-  const int d = (k > l) ? k - l : l - k, sm = k + l;
-  if (ti == 0 && tj == 0) return 0.5 * ((sys == 0) ? (c0[d] + c0[sm]) : (c0[d] - c0[sm]));   // cos cos | sin sin
-  if (ti == 1 && tj == 1) return 0.5 * ((sys == 0) ? (c2[d] - c2[sm]) : (c2[d] + c2[sm]));   // n sin n sin | n cos n cos
-  // mixed: even: cos(k') n sin(l') = n (sin((l'+k')x) + sin((l'-k')x))/2;  odd: sin(k') n cos(l') = n (sin((k'+l')x) + sin((k'-l')x))/2
-  const int kp = ti ? l : k, lp = ti ? k : l;      // kp: harmonic of the plain function, lp: of the n-times one
-  const int dd = (sys == 0) ? (lp - kp) : (kp - lp);
-  const double sd = (dd > 0) ? s1[dd] : (dd < 0) ? -s1[-dd] : 0.0;
-  return 0.5 * (s1[sm] + sd);
-}
-
-__device__ __attribute__((noinline)) void a0_frame(const LsArgs& A, double* lds_, int f_) {
-  const int f = uni(f_);
-  const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lcol = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), sys = wave >> 2, w4 = wave & 3;
-  double* lds = uni(lds_);
-  const int K = uni(A.frame_K[f]), Kc = 2 * K + 1, m = (Kc + 1 + 15) >> 4, is = Kc - 16 * (m - 1), nts = m * (m + 1) / 2;
-  const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
-  const int N = 2 * wl + 1;
-  const double f0 = uni(A.frame_f0[f]);
-  // ---- LDS
-  double* tab = lds;                                   // [TZ_NQ][TZ_TB]
-  double* part = tab + TZ_NQ * TZ_TB;                  // [TZ_NCH][TZ_NQ][TZ_TB]
-  double* W2 = part + TZ_NCH * TZ_NQ * TZ_TB;          // [wl+1] each
-  double* PA = W2 + 520;
-  double* PB = PA + 520;
-  double* win = PB + 520;                              // [N]
-  double* sig = win + 64 * CI_NCH;                     // [N]
-  double* Pan = lds;                                   // [2][A0_M][TL_TILE]  (over the tables, after the fill)
-  double* Wt = Pan + 2 * A0_M * TL_TILE;               // [2][A0_M][TL_TILE]
-  double* Ldl = sig + 64 * CI_NCH;                     // [2][TL_TILE]
-  double* post = Ldl + 2 * TL_TILE;                    // [2][8 * 32]
-  double* dumpD = post + 512;                          // [2][64]
-  double* zs = dumpD + 128;                            // [2][64]
-  double* zv = zs + 128;                               // [2][16 * A0_M]
-  double* xv = zv + 2 * 16 * A0_M;                     // [2][16]
-  double* dorig = xv + 32;                             // [2][16 * A0_M]
-  double* solv = dorig + 2 * 16 * A0_M;                // [2][16 * A0_M]   solutions of the two systems
-  double* sh = solv + 2 * 16 * A0_M;                   // 16
-  int* flags = (int*)(sh + 16);                        // [2] step counters of the two diagonal pipelines
-  double* xs = sh + 18;                                // 4 * Kcmax
-  unsigned long long* dbg = uni(A.debug);
-  unsigned long long t_prev = 0;
-  if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
-
-  for (int t = tid; t < N; t += TL_THREADS) {
-    win[t] = window_value(1, t, N);
-    sig[t] = uni(A.s)[(size_t)(c - wl) + t];
-  }
-  if (tid < 2) flags[tid] = 0;
-  __syncthreads();
-  STAMP(0);
-  toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, K, wl, f0 * (2.0 * M_PI / uni(A.fs)), tid, TZ_TB, TZ_NCH);
-  const double ssq = sh[0];
-
-  // ---- this wave's tiles of its system (numbered column by column, tile y on wave y % 4, slot y / 4)
-  d4 acc[A0_NS];
-  int tP[A0_NS], tQ[A0_NS];
-  bool live[A0_NS];
-#pragma unroll
-  for (int sl = 0; sl < A0_NS; ++sl) {
-    const int y = sl * 4 + w4;
-    live[sl] = y < nts;
-    int P = 0, Q = 0;
-    if (live[sl]) {
-      int start = 0;
-      while (Q + 1 < m && start + (m - Q) <= y) { start += m - Q; ++Q; }
-      P = Q + (y - start);
-    }
-    tP[sl] = __builtin_amdgcn_readfirstlane(P);
-    tQ[sl] = __builtin_amdgcn_readfirstlane(Q);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      acc[sl][r] = live[sl] ? a0_entry(tab, ssq, sys, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, K, Kc) : 0.0;
-    if (live[sl] && tP[sl] == tQ[sl]) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (lq + 4 * r == lcol) dorig[sys * 16 * A0_M + 16 * tP[sl] + lcol] = acc[sl][r];
-    }
-  }
-  __syncthreads();   // the tables are dead: their space becomes panel / inverse storage
-  STAMP(2);
-
-#define A0_UPDATE(sl)                                                                   \
-  {                                                                                     \
-    const double* ar = Pan + (sys * A0_M + tP[sl]) * TL_TILE;                           \
-    const double* br = Pan + (sys * A0_M + tQ[sl]) * TL_TILE;                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                  \
-      const int o = (4 * ks + lq) * TL_LD + lcol;                                       \
-      acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[o], -br[o], acc[sl], 0, 0, 0);  \
-    }                                                                                   \
-  }
-  for (int jb = 0; jb < m; ++jb) {
-    const int yd = jb * m - jb * (jb - 1) / 2;   // the diagonal tile of this stage
-    d4 Rt = (d4){0, 0, 0, 0};
-    bool mine = false;
-#pragma unroll
-    for (int sl = 0; sl < A0_NS; ++sl) {
-      if (!live[sl] || tP[sl] != jb || tQ[sl] != jb) continue;
-      if (jb > 0) A0_UPDATE(sl)
-      Rt = acc[sl];
-      mine = true;
-    }
-    if (mine)
-      diag_Dr(Rt, post + sys * 256, flags + sys, 16 * jb, dumpD + sys * 64, Ldl + sys * TL_TILE, jb == m - 1);
-    else if (w4 == ((yd + 1) & 3))
-      diag_Zr(post + sys * 256, flags + sys, 16 * jb, zs + sys * 64, Wt + (sys * A0_M + jb) * TL_TILE,
-              dorig + sys * 16 * A0_M + 16 * jb, (jb == m - 1) ? is : 16, uni(A.fault));
-    STAMP(10);
-    if (jb > 0) {
-#pragma unroll
-      for (int sl = 0; sl < A0_NS; ++sl) {
-        if (!live[sl] || tQ[sl] < jb || (tP[sl] == jb && tQ[sl] == jb)) continue;
-        A0_UPDATE(sl)
-      }
-    }
-    STAMP(8);
-    __syncthreads();  // (A)
-    STAMP(6);
-#pragma unroll
-    for (int sl = 0; sl < A0_NS; ++sl) {   // panel tiles: X = T W^T, published k-major
-      if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
-      double* tr = Pan + (sys * A0_M + tP[sl]) * TL_TILE;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tr[lcol * TL_LD + lq + 4 * r] = acc[sl][r];
-      __builtin_amdgcn_wave_barrier();
-      const double* wt = Wt + (sys * A0_M + jb) * TL_TILE;
-      d4 x = (d4){0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int o = (4 * ks + lq) * TL_LD + lcol;
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[o], wt[o], x, 0, 0, 0);
-      }
-      acc[sl] = x;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tr[lcol * TL_LD + lq + 4 * r] = x[r];
-    }
-    STAMP(7);
-    __syncthreads();  // (C)
-  }
-#undef A0_UPDATE
-  STAMP(3);
-
-  // ---- back substitution  L^T x = y,  y = row `is` of the last tile row
-  double* zvs = zv + sys * 16 * A0_M;
-#pragma unroll
-  for (int sl = 0; sl < A0_NS; ++sl) {
-    if (!live[sl] || tP[sl] != m - 1 || tQ[sl] == m - 1) continue;
-    if (lq == (is & 3)) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r == (is >> 2)) zvs[16 * tQ[sl] + lcol] = acc[sl][r];
-    }
-  }
-  if (w4 == 0 && lane < 16) zvs[16 * (m - 1) + lane] = (lane < is) ? Ldl[sys * TL_TILE + is * TL_LD + lane] : 0.0;
-  __syncthreads();
-  for (int P = m - 1; P >= 0; --P) {
-    {   // x_P = W_PP^T z_P: the 256 threads of the system's four waves, thread (i, k) one term of row i
-      const int ts = tid & 255, i = ts >> 4, k = ts & 15;
-      double x = (k >= i) ? Wt[(sys * A0_M + P) * TL_TILE + i * TL_LD + k] * zvs[16 * P + k] : 0.0;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o);
-      if (k == 0) {
-        xv[sys * 16 + i] = x;
-        solv[sys * 16 * A0_M + 16 * P + i] = x;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int sl = 0; sl < A0_NS; ++sl) {
-      if (!live[sl] || tP[sl] != P || tQ[sl] == P) continue;
-      double sr = 0;   // sum_i L[i][j] x[i] over this lane's rows i = lq + 4r
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sr += acc[sl][r] * xv[sys * 16 + lq + 4 * r];
-      sr += __shfl_xor(sr, 16);
-      sr += __shfl_xor(sr, 32);
-      if (lq == 0) zvs[16 * tQ[sl] + lcol] -= sr;
-    }
-    __syncthreads();
-  }
-  STAMP(4);
-  // ---- back to the complex amplitudes and slopes in the order of the complex code: [negative | DC | positive]
-  {
-    const double* ev = solv;                       // u_0..u_K, q_1..q_K
-    const double* od = solv + 16 * A0_M;           // v_1..v_K, p_0..p_K
-    for (int col = tid; col < Kc; col += TL_THREADS) {
-      const int h = (col < K) ? -(col + 1) : (col - K), k = (h < 0) ? -h : h;
-      double ar, ai, br, bi;
-      if (k == 0) { ar = ev[0]; ai = 0.0; br = od[K]; bi = 0.0; }
-      else {
-        ar = 0.5 * ev[k]; ai = -0.5 * od[k - 1];
-        br = 0.5 * od[K + k]; bi = -0.5 * ev[K + k];
-        if (h < 0) { ai = -ai; bi = -bi; }
-      }
-      xs[2 * col] = ar; xs[2 * col + 1] = ai;
-      xs[2 * (Kc + col)] = br; xs[2 * (Kc + col) + 1] = bi;
-    }
-  }
-  __syncthreads();
-  write_record(A, xs, sh, nullptr, f, K, inst, c, f0, false);
-  STAMP(5);
-}
-
 // Frames bucketed by the number of tile rows of their system (see LsArgs::cls).
 __device__ inline int frame_class(int n) {
   const int nt = (2 * (2 * n + 1) + 1 + 15) >> 4;
@@ -848,7 +620,7 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
     const int item = nxt;                                                                \
     __syncthreads();                                                                     \
     if (item >= A.cls[C]) break;                                                         \
-    if (A.mode == 0) a0_frame(A, lds, A.cls[16 + (size_t)C * A.n_frames + item]);                          \
+    if (A.mode == 0) a0_frame<A0_NS, A0_M, 2>(A, lds, A.cls[16 + (size_t)C * A.n_frames + item], TZ_TB, TZ_NCH, 520, 64 * CI_NCH);                          \
     else tile_frame<NSV, 1>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);               \
   }
   RUN_CLASS(12, 5)   // 91 tiles
@@ -900,6 +672,8 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int TS = 32;
   const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
   if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+  if (a0_lds_doubles(A0_M, 2, TZ_TB, TZ_NCH, 520, 64 * CI_NCH, Kcmax) * sizeof(double) > lds_bytes)
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (adaptation 0, tile variant)");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(eaqhm_ls_tile_kernel, dim3(grid), dim3(TL_THREADS), lds_bytes, ctx->stream, A, TS, ldx_max);
   HIP_TRY(ctx, hipGetLastError());
