@@ -248,6 +248,14 @@ def main():
     achieved = float(allr[:, 3].sum()) / ls_total_s / 1e12 if ls_total_s > 0 else 0.0
     srer = [float(v) for v in eng.SRER]
     kernel = "eaqhm_ls_tile_kernel" if fs <= 16000 else "eaqhm_ls_mfma_kernel"
+    # Adaptation 0 is solved by a cheaper algorithm than the one F(N, Kc) counts (closed-form Gramian, two real systems of
+    # half the order), so its launch "achieves" more algorithmic flops per second than the matrix pipe does work: the
+    # rate of the adaptation >= 1 launches alone (rank 0) is reported next to the overall one
+    ls_a = [a for (a, st, e0, e1) in eng.timeline if st == "ls"]
+    t_ge1 = sum(t for a, t in zip(ls_a, ls_ms) if a >= 1) / 1e3
+    f_ge1 = sum(flops_per_launch[a] for a in ls_a if a >= 1 and a < len(flops_per_launch))
+    frac_ge1 = (f_ge1 / t_ge1 / 1e12 / PEAK_FP64_TFLOPS) if t_ge1 > 0 else None
+    ms0 = [t for a, t in zip(ls_a, ls_ms) if a == 0]
     # HBM traffic of that kernel: not measurable from inside this process; taken from the committed rocprofv3 PMC
     # passes of this same command and workload (profiles/r02_<workload>/pmc_hbm_traffic.json), N = 1 only
     traffic, traffic_src = None, None
@@ -264,6 +272,8 @@ def main():
                 "algorithmic_bytes_launch0": bytes_per_launch[0],
                 "flops_per_launch_mean": flops_step / max(len(flops_per_launch), 1),
                 "launch_ms_mean": float(np.mean(ls_ms)) if ls_ms else None,
+                "launch_ms_adaptation0": float(np.mean(ms0)) if ms0 else None,
+                "frac_adaptation_ge1_launches": frac_ge1,
                 "launches_timed": len(ls_ms),
                 "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None,
                 "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None,

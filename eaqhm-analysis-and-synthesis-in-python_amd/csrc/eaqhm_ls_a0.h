@@ -21,7 +21,7 @@
 namespace eaqhm {
 
 // entry (gi, gj) of system `sys` (0 even, 1 odd), order Kc + 1 with the right-hand side as row / column Kc
-__device__ inline double a0_entry(const double* tab, int TB, double ssq, int sys, int gi, int gj, int K, int Kc) {
+__device__ __attribute__((noinline)) double a0_entry(const double* tab, int TB, double ssq, int sys, int gi, int gj, int K, int Kc) {
   if (gi > Kc || gj > Kc) return (gi == gj) ? 1.0 : 0.0;      // identity padding behind the right-hand side
   if (gi == Kc && gj == Kc) return ssq;
   const double* c0 = tab; const double* s1 = tab + TB; const double* c2 = tab + 2 * TB;

@@ -318,6 +318,53 @@ def test_against_oracle_seeded_signal(amd, params):
     assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= loose * TOL_PH_RAD
 
 
+def test_long_windows_against_oracle(amd):
+    """A low voice at 32 kHz (f0 86-94 Hz, 'male' limits): windows of 1020-1120 samples — longer than the 1024-sample
+    chunks of the zero counts and than the 16 x 64-sample masks the register-resident kernel is laid out for — and
+    343-371 basis columns, i.e. real systems of 22-24 tile rows at adaptation 0: beyond what eaqhm_ls_a0big_kernel
+    holds in registers, so that launch takes the complex system through memory; adaptation 1 runs the large-frame
+    kernel with bridged gaps in windows that straddle two chunk boundaries."""
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    fs, n = 32000, 5400
+    rng = np.random.default_rng(7)
+    t = np.arange(n) / fs
+    f0 = 90.0 + 4.0 * np.sin(2 * np.pi * 1.3 * t)
+    phi = 2 * np.pi * np.cumsum(f0) / fs
+    x = np.zeros(n)
+    for k in range(1, 160):
+        x += k ** -1.2 * np.cos(k * phi + rng.uniform(0, 2 * np.pi))
+    x += rng.standard_normal(n) * np.sqrt(np.mean(x ** 2)) * 10 ** (-45 / 20)
+    s = np.round(0.25 * x / np.abs(x).max() * 32767) / 32768.0
+    tt = np.arange(0, n / fs, 0.001)
+    track = np.column_stack([tt, 90.0 + 4.0 * np.sin(2 * np.pi * 1.3 * tt), np.ones_like(tt)])
+    grid = prologue.resample_track(track, np.arange(0, n - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "male")
+    for fr in frames:                       # every instant voiced speech: the geometry is what is under test
+        fr.isSpeech = fr.isVoiced = True
+    ti5 = np.array([f.ti for f in frames])
+    ones = np.ones(len(frames))
+    # step 60: the unanalysed margin analysisWindow * step (functions.py:180) is then longer than half a window
+    ref = O.analyse(s, fs, grid, ti5, ones, ones, fstep, f0min=70, maxAdpt=1, step=60, pitchPeriods=3, analysisWindow=32,
+                    partials=0)
+    plan = FramePlan(n, fs, grid, frames, fstep, 60, 3, 32, 0)
+    assert (2 * plan.frame_wl + 1).max() > 1024 and ((2 * plan.frame_K + 2 + 15) // 16).min() > 19
+    eng = DeviceAnalysis(s, s, plan, 70, 1)
+    eng.run()
+    fin = eng.final_arrays()
+    assert len(eng.SRER) == len(ref["SRER"])
+    assert np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9
+    m = ref["am"] != 0
+    assert np.mean((fin["am"] != 0) == m) >= 0.999
+    both = m & (fin["am"] != 0)
+    assert np.abs(fin["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
+    strong = both & (ref["am"] > 1e-6 * ref["am"].max())      # the angle of a vanishing partial is ill-conditioned
+    assert np.abs(wrap(fin["pk"][strong] - ref["pk"][strong])).max() <= TOL_PH_RAD
+
+
 def test_entry_point_with_own_swipe(amd, sa19_golden):
     """The complete drop-in call — wav in, (s_recon, SRER, DetComponents, time) out — with the pitch track
     estimated by the package's own SWIPE' restatement (no fixture)."""
