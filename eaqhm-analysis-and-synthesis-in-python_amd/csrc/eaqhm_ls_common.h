@@ -190,23 +190,6 @@ __device__ inline void toeplitz_rhs(const double* tab, int TB, int p, int b, int
   if (h < 0) im = -im;                                      // r[-h] = conj r[h]
 }
 
-// entry (gi, gj) of the stacked system  Y^H Y,  Y = w [E | n E | s]  (the layout of eaqhm_ls_tile_kernel)
-__device__ inline void toeplitz_entry(const double* tab, int TB, double ssq, int gi, int gj, int n, int Kc, double& re,
-                                      double& im) {
-  re = 0.0; im = 0.0;
-  const int sigc = 2 * Kc;
-  if (gi > sigc || gj > sigc) return;                       // padding: set by the caller
-  if (gi == sigc && gj == sigc) { re = ssq; return; }
-  if (gi == sigc || gj == sigc) {                           // right-hand-side row (or its mirror column: conjugate)
-    const int c = (gi == sigc) ? gj : gi;
-    toeplitz_rhs(tab, TB, (c >= Kc) ? 1 : 0, (c >= Kc) ? c - Kc : c, n, re, im);
-    if (gj == sigc) im = -im;
-    return;
-  }
-  toeplitz_gram(tab, TB, ((gi >= Kc) ? 1 : 0) + ((gj >= Kc) ? 1 : 0), (gi >= Kc) ? gi - Kc : gi, (gj >= Kc) ? gj - Kc : gj,
-                n, re, im);
-}
-
 // logical column cc of the chunk rows of sample pair el lives at XCOL(cc, el): the 16 lanes that write one column of 16
 // different pairs hit 16 different LDS banks, and the MFMA operand reads (column (lcol + row / 2) & 15) stay conflict-free
 #define XCOL(cc, el) (((cc) & ~15) | (((cc) + (el)) & 15))

@@ -17,7 +17,8 @@
 //          loaded directly, phase = running sum (16-lane DPP scan + per-slot carry); the pair shares its sincos
 //          because the negative-frequency column at u is the time-reversed positive one (functions.py:284-285);
 //          contracted with v_mfma_f64_16x16x4_f64, LDS operand reads software-pipelined one k-step ahead
-//   B0     adaptation 0: no basis at all — the Gramian in closed form from Toeplitz tables (eaqhm_ls_common.h)
+//   B0     adaptation 0: no basis at all — the Gramian in closed form from Toeplitz tables, then two real systems of
+//          half the order factorised side by side (a0_frame, eaqhm_ls_a0.h)
 //   C      right-looking tile Cholesky with look-ahead, 2 workgroup barriers per tile row: trailing update with the
 //          previous panel (the next diagonal tile first); its owner wave factorises that tile on the matrix cores
 //          (diag_D: 2x2 block pivots, one rank-2 MFMA per plane and step, rows handed round by ds_bpermute) while a
@@ -50,13 +51,13 @@ __device__ inline void sys_tile_of(int x, int& P, int& Q) {
   while (P * (P + 1) / 2 > x) --P;
   Q = x - P * (P + 1) / 2;
 }
-// (adaptation 0: the Gramian in closed form — toeplitz_tables / toeplitz_entry in eaqhm_ls_common.h)
+// (adaptation 0: closed-form Gramian and two real systems — eaqhm_ls_a0.h; table sizes for frames of this kernel)
 #define TZ_TB 104     // table stride: m = 0 .. 2 n <= 102
 #define TZ_NCH 8      // chunks of the t range (deterministic two-level summation)
 
 // One frame with NS tiles per wave.  Not inlined: each register budget gets its own register allocation (inlining
 // the five budgets into one kernel body spills several hundred VGPRs).
-template <int NS, int MODE>
+template <int NS>
 __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, int ldx_max_, double* lds, int f_) {
   const int TS = uni(TS_), ldx_max = uni(ldx_max_), f = uni(f_);
   const int tid = threadIdx.x, nt_thr = TL_THREADS;
@@ -89,8 +90,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   const int Npad = ((uni(A.Nmax) + 63) >> 6) << 6;
   double* Qs = uni(A.scratch) + (size_t)blockIdx.x * (size_t)uni((int)A.scratch_stride);  // bridged fm[j][t]
   double* Rs = Qs + (size_t)Npad * uni(A.nmax);                                           // bridged am[j][t]
-  constexpr int mode = MODE;
-  const bool seeds = (mode == 1) && (uni((int)(A.any_seed && (*A.any_seed != 0))) != 0);
+  const bool seeds = uni((int)(A.any_seed && (*A.any_seed != 0))) != 0;
   // phases are q * (2 pi / fs) here, (2 pi q) / fs in the reference (functions.py:513, :453): one rounding each way,
   // <= 2 ulp of the phase apart, and no IEEE division per basis sample
   const double w1 = uni(2.0 * M_PI / A.fs);
@@ -109,7 +109,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
   } while (0)
 
   {
-    const int n = uni((mode == 0) ? A.frame_K[f] : A.ncol[f]);
+    const int n = uni(A.ncol[f]);
     const int Kc = 2 * n + 1, Ms = 2 * Kc + 1;   // stacked columns incl. the signal
     const int nt = (Ms + 15) >> 4;
     const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
@@ -117,21 +117,20 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     const int ldx = (nt << 4) + ((nt & 1) ? 0 : 16);  // ≡ 16 (mod 32): MFMA operand reads hit disjoint bank halves
     const int ntiles = nt * (nt + 1) / 2;
     const int is = 2 * Kc - 16 * (nt - 1);  // position of the signal column inside the last tile row (2,6,10,14)
-    const double f0 = uni((mode == 0) ? A.frame_f0[f] : A.f0_stale);
-    const int* mycols = (mode == 1) ? (uni(A.cols) + (size_t)f * uni(A.Kmax)) : nullptr;
+    const double f0 = uni(A.f0_stale);
+    const int* mycols = uni(A.cols) + (size_t)f * uni(A.Kmax);
     const int npairs = mid + 1;  // pairs e = 0..mid: (u, v) = (e-1, N-1-e)
 
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     // region U may hold tiles of the previous frame: make the basis chunk finite and its padding zero
-    if constexpr (MODE == 1)
-      for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
+    for (int q = tid; q < 2 * TS * ldx_max; q += nt_thr) Xre[q] = 0.0;
     for (int t = tid; t < N; t += nt_thr) {
-      win[t] = window_value(mode == 0, t, N);
+      win[t] = window_value(false, t, N);
       sig[t] = sA[(size_t)(c - wl) + t];
     }
     __syncthreads();
     int* gappy = (int*)(masks + (size_t)52 * CI_NCH);   // [52] flags
-    if (mode == 1) prepare_slots<CI_STRIDE, TL_WAVES>(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, CI_NCH);
+    prepare_slots<CI_STRIDE, TL_WAVES>(A, Qs, Rs, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, CI_NCH);
     STAMP(0);
 
     // system tiles of this wave
@@ -165,31 +164,8 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
     }
 
     // ================= Gramian =================
-    if constexpr (MODE == 0) {   // closed form (Toeplitz tables), see toeplitz_tables
-      double* tab = U;                                   // [TZ_NQ][TZ_TB]
-      double* part = tab + TZ_NQ * TZ_TB;                // [TZ_NCH][TZ_NQ][TZ_TB]
-      double* W2 = part + TZ_NCH * TZ_NQ * TZ_TB;        // [wl+1] each
-      double* PA = W2 + 64 * CI_NCH / 2 + 8;
-      double* PB = PA + 64 * CI_NCH / 2 + 8;
-      toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, n, wl, f0 * w1, tid, TZ_TB, TZ_NCH);
-      const double ssq = sh[0];
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-        if (!live[sl]) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double re, im;
-          toeplitz_entry(tab, TZ_TB, ssq, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, n, Kc, re, im);
-          accR[sl][r] = re;
-          accI[sl][r] = im;
-        }
-      }
-      __syncthreads();   // region U (tables) is reused as tile storage below
-      STAMP(2);
-    }
     // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid, taken from the centre outwards so that the phase
     // integral of functions.py:508-515 relative to the centre is a running sum
-    if constexpr (MODE == 1)
     for (int d0 = 0; d0 < npairs; d0 += PE) {
       // logical column cc of chunk rows (2*el, 2*el+1) lives at XCOL(cc, el): the 16 lanes that write one column
       // of 16 different pairs hit 16 different banks, and MFMA operand reads stay conflict-free
@@ -200,7 +176,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         const int u = mid - d - 1, v = mid + d;
         double su = 0, cu = 1, sv, cv;
         double pur = 0, pui = 0, nur = 0, nui = 0, pvr, pvi, nvr, nvi;  // positive / negative column values
-        if (mode == 1) {
+        {
           double* cj = ci + j * CI_STRIDE;
           const double* fb = ((const double**)cj)[2];   // bridged copy or the track itself (prepare_slots)
           const double* ab = ((const double**)cj)[3];
@@ -228,15 +204,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           const double rv = (eps + av) * ainv, ru1 = (eps + au1) * ainv;
           pvr = rv * cv;                      pvi = rv * sv;
           nvr = ru1 * (cu * pr - su * pi);    nvi = ru1 * (cu * pi + su * pr);
-        } else {  // adaptation 0: exp(j 2 pi k f0 n / fs), negative column = conjugate (functions.py:453-454)
-          if (!act) continue;
-          const double fk = (double)(j + 1) * f0;
-          if (u >= 0) {
-            sincos_cw(((double)(u - mid) * fk) * w1, &su, &cu);
-            pur = cu; pui = su; nur = cu; nui = -su;
-          }
-          sincos_cw(((double)(v - mid) * fk) * w1, &sv, &cv);
-          pvr = cv; pvi = sv; nvr = cv; nvi = -sv;
         }
         double* xr = Xre + (2 * el) * ldx;
         double* xi = Xim + (2 * el) * ldx;
@@ -360,7 +327,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       __syncthreads();
       STAMP(2);
     }
-    if constexpr (NM3 > 0 && MODE == 1) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
+    if constexpr (NM3 > 0) {   // Re = P1 + P2,  Im = aR bI - aI bR = P3 + P1 - P2
 #pragma unroll
       for (int sl = 0; sl < NM3; ++sl) {
         const d4 p1 = accR[sl], p2 = acc3[sl];
@@ -621,7 +588,7 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
     __syncthreads();                                                                     \
     if (item >= A.cls[C]) break;                                                         \
     if (A.mode == 0) a0_frame<A0_NS, A0_M, 2>(A, lds, A.cls[16 + (size_t)C * A.n_frames + item], TZ_TB, TZ_NCH, 520, 64 * CI_NCH);                          \
-    else tile_frame<NSV, 1>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);               \
+    else tile_frame<NSV>(A, TS, ldx_max, lds, A.cls[16 + (size_t)C * A.n_frames + item]);               \
   }
   RUN_CLASS(12, 5)   // 91 tiles
   RUN_CLASS(10, 4)   // 78 tiles
