@@ -250,55 +250,45 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
           Xre[row * ldx + XCOL(Kc, el)] = sv;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
         }
         __syncthreads();
-        // Touch the track lines the NEXT chunk's build will read (per slot four runs of fm and four of am), issued now
-        // and consumed after the contraction: the build then finds its values in L1/L2 instead of waiting a DRAM round
-        // trip per chunk with the matrix pipe idle.
-        double pf = 0.0;
-        {
-          const int d1 = d0 + PE, q = tid & 7;
-          if (d1 <= mid)
-            for (int jp = tid >> 3; jp < n; jp += nt >> 3) {
-              const double* base = ((const double**)(ci + jp * MF_CI))[2 + (q >> 2)];   // fm runs, then am runs
-              const int ext = 15 + (q >> 2);
-              int off = ((q & 3) == 0) ? (mid - d1 - ext) : ((q & 3) == 1) ? (mid - d1) : ((q & 3) == 2) ? (mid + d1) : (mid + d1 + ext);
-              off = (off < 0) ? 0 : (off > N - 1) ? (N - 1) : off;
-              pf += base[off];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // (touching the next chunk's track lines here, as the tile kernel does, costs 5 % in this kernel: 630 vs 598 ms)
         // ---- contraction of the chunk (only the k-steps that hold samples: the rest of the last chunk has weight 0)
         const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;
         const int ksn = (pcs + 1) >> 1;
         const int lq = lane >> 4, lcol = lane & 15;
         const double* wrow = Wp + lq;
 #ifndef EAQHM_EXPERIMENT_NOCONTRACT   /* (timing experiment: no matrix products; wrong results) */
-#pragma unroll
-        for (int sl = 0; sl < MF_NT; ++sl) {
-          if (!live[sl]) continue;
-          const int ca = 16 * tI[sl], cb = 16 * tJ[sl];
+        {
+          // k-step outermost: the operands of both tiles and the three weights are requested together, then the 18
+          // independent MFMAs follow (row = 4 ks + lq, column rotation (lcol + row / 2) & 15)
           const int sw0 = lcol + (lq >> 1);
           int rb = lq * ldx;
-          // (requesting the operands of k-step ks+1 ahead of the MFMAs of k-step ks, as the tile kernel does, is slower
-          //  here: 663 vs 630 ms per launch on 12 s of the 48 kHz workload — nine independent MFMAs per k-step and the
-          //  second wave of the SIMD already cover the LDS latency)
 #pragma clang loop unroll(disable)
-          for (int ks = 0; ks < ksn; ++ks) {   // row = 4 ks + lq, column rotation (lcol + row / 2) & 15
+          for (int ks = 0; ks < ksn; ++ks) {
             const int sw = (sw0 + 2 * ks) & 15;
-            const double aR = Xre[rb + ca + sw], aI = Xim[rb + ca + sw], bR = Xre[rb + cb + sw], bI = Xim[rb + cb + sw];
-            rb += 4 * ldx;
-            const double sA = aR + aI;
+            double aR[MF_NT], aI[MF_NT], bR[MF_NT], bI[MF_NT];
 #pragma unroll
-            for (int w = 0; w < 3; ++w) {
-              const double wv = wrow[w * 32 + 4 * ks];
-              const double bRw = wv * bR, bIw = wv * bI;
-              P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, bRw, P1[sl][w], 0, 0, 0);
-              P2[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, bIw, P2[sl][w], 0, 0, 0);
-              P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA, bIw - bRw, P3[sl][w], 0, 0, 0);
+            for (int sl = 0; sl < MF_NT; ++sl) {
+              const int ca = 16 * tI[sl], cb = 16 * tJ[sl];
+              aR[sl] = Xre[rb + ca + sw]; aI[sl] = Xim[rb + ca + sw]; bR[sl] = Xre[rb + cb + sw]; bI[sl] = Xim[rb + cb + sw];
+            }
+            const double w0 = wrow[4 * ks], w1v = wrow[32 + 4 * ks], w2 = wrow[64 + 4 * ks];
+            rb += 4 * ldx;
+#pragma unroll
+            for (int sl = 0; sl < MF_NT; ++sl) {
+              if (!live[sl]) continue;
+              const double sA = aR[sl] + aI[sl];
+#pragma unroll
+              for (int w = 0; w < 3; ++w) {
+                const double wv = (w == 0) ? w0 : (w == 1) ? w1v : w2;
+                const double bRw = wv * bR[sl], bIw = wv * bI[sl];
+                P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[sl], bRw, P1[sl][w], 0, 0, 0);
+                P2[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[sl], bIw, P2[sl][w], 0, 0, 0);
+                P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA, bIw - bRw, P3[sl][w], 0, 0, 0);
+              }
             }
           }
         }
 #endif
-        asm volatile("" ::"v"(pf));   // (the touched values themselves are not used)
         __syncthreads();
       }
 
