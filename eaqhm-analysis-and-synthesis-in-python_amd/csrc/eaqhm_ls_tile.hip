@@ -249,21 +249,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       STAMP(12);
       __syncthreads();
       STAMP(1);
-      // Touch the track lines the NEXT chunk's build will read (four runs of <= 136 bytes per slot: at most eight
-      // 128-byte lines), one load per thread, issued now and consumed after the contraction: the build then finds
-      // its six values per item in L1/L2 instead of waiting a DRAM round trip per chunk with the matrix pipe idle.
-      double pf = 0.0;
-      {
-        const int d1 = d0 + PE, jp = tid >> 3, q = tid & 7;
-        if (d1 <= mid && jp < n) {
-          const double* base = ((const double**)(ci + jp * CI_STRIDE))[2 + (q >> 2)];   // fm runs, then am runs
-          const int ext = 15 + (q >> 2);
-          int off = ((q & 3) == 0) ? (mid - d1 - ext) : ((q & 3) == 1) ? (mid - d1) : ((q & 3) == 2) ? (mid + d1) : (mid + d1 + ext);
-          off = (off < 0) ? 0 : (off > N - 1) ? (N - 1) : off;
-          pf = base[off];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
       const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;   // sample pairs in this chunk
       const int ksl = (pcs + 1) >> 1;                             // k-steps (4 rows each) that hold samples
 #pragma unroll
@@ -323,7 +308,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           aR = naR; aI = naI; bR = nbR; bI = nbI;
         }
       }
-      asm volatile("" ::"v"(pf));   // (the prefetched value itself is not used)
       __syncthreads();
       STAMP(2);
     }
