@@ -439,7 +439,7 @@ __device__ __attribute__((always_inline)) inline void diag_Zr(const double* post
 // nt^3/6 tile reads, 20 MB per frame, 3-6 TB per launch measured, three times what HBM delivers while the MFMAs of
 // the update would need it.  So the update is applied to CH_W columns at once:
 //   (1) block update   T[P][Q0+c] -= sum_{j<Q0} L[P][j] L[Q0+c][j]^H  for the CH_W columns of the block and all rows
-//       P >= Q0: a wave takes CH_RB rows at a time, loads each A tile L[P][j] ONCE for the four columns (the four B
+//       P >= Q0: a wave takes CH_RB rows at a time, loads each A tile L[P][j] ONCE for the columns of the block (the B
 //       tiles of a j are shared by all waves: L1/L2), accumulates in registers and writes the tiles back in place;
 //   (2) the columns of the block one after another, as before, with the j-loop running over the block's own earlier
 //       columns only: the diagonal tile is factorised and inverted in LDS by the whole workgroup (diag_coop) and the
@@ -447,8 +447,10 @@ __device__ __attribute__((always_inline)) inline void diag_Zr(const double* post
 // The right-hand side rides along as the last tile row, so the forward substitution is free; the back
 // substitution walks the tile columns from the stored factor.
 #define CH_MB 6          // tiles per wave, column and register group (single-column part)
-#define CH_W 4           // tile columns per block
+#define CH_W 3           // tile columns per block
 #define CH_RB 2          // tile rows per wave and register group of the block update
+// (measured on the 48 kHz workload, ms per adaptation>=1 launch: 2 x 3 tiles with three real products per complex one
+//  576; 1 x 4: 581; 1 x 5: 578; 3 x 2: 584; 2 x 4 with four products — two accumulators per tile — 593; 2 x 4 with three: 622, spills)
 #define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
 #define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32 + 16)
@@ -483,14 +485,16 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
    if (Q0 > 0) {
 #endif
     // ---- (1) block update of columns Q0 .. Q0+Wc-1 from the columns before the block.  Rows P = Q0 + wave + 8 x,
-    //      CH_RB of them per register group; two accumulators per tile (re, -im), four real products per complex one.
+    //      CH_RB of them per register group; three accumulators per tile, three real products per complex one.
     const int ngr = (nt - Q0 + 8 * CH_RB - 1) / (8 * CH_RB);
     for (int g = 0; g < ngr; ++g) {
-      d4 cR[CH_RB][CH_W], cI[CH_RB][CH_W];
+      d4 cR[CH_RB][CH_W], cI[CH_RB][CH_W], c3[CH_RB][CH_W];
 #pragma unroll
       for (int m = 0; m < CH_RB; ++m)
 #pragma unroll
-        for (int c = 0; c < CH_W; ++c) { cR[m][c] = (d4){0, 0, 0, 0}; cI[m][c] = (d4){0, 0, 0, 0}; }
+        for (int c = 0; c < CH_W; ++c) {
+          cR[m][c] = (d4){0, 0, 0, 0}; cI[m][c] = (d4){0, 0, 0, 0}; c3[m][c] = (d4){0, 0, 0, 0};
+        }
       const int Pg = Q0 + wave + 8 * CH_RB * g;
       if (Pg < nt) {
         // software-pipelined over it = 4 j + ks: the operands of step it+1 are requested before the MFMAs of step it
@@ -525,10 +529,10 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
 #pragma unroll
             for (int c = 0; c < CH_W; ++c) {
               if (c >= Wc || Q0 + c > P) continue;   // (tile above the diagonal / beyond the last column)
+              // P1 = re re, P2 = im im, P3 = (re + im)(im' - re'):  Re = P1 + P2,  -Im = P3 + P1 - P2
               cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bR[c], cR[m][c], 0, 0, 0);
-              cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[m], bI[c], cR[m][c], 0, 0, 0);
-              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bI[c], cI[m][c], 0, 0, 0);
-              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI[m], bR[c], cI[m][c], 0, 0, 0);
+              c3[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[m], bI[c], c3[m][c], 0, 0, 0);
+              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m] + aI[m], bI[c] - bR[c], cI[m][c], 0, 0, 0);
             }
           }
 #pragma unroll
@@ -548,8 +552,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int o = (lq + 4 * r) * 16 + lcol;
-              Ct[o] -= cR[m][c][r];
-              Ct[256 + o] += cI[m][c][r];
+              Ct[o] -= cR[m][c][r] + c3[m][c][r];
+              Ct[256 + o] += cI[m][c][r] + (cR[m][c][r] - c3[m][c][r]);
             }
           }
         }

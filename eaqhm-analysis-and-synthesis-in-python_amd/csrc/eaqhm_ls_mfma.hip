@@ -29,7 +29,9 @@ namespace eaqhm {
 #define MF_A0_M 19   // adaptation 0 on chip: real systems of up to 19 tile rows (Kc + 1 <= 304)
 #define MF_A0_NCH 4
 #define MF_CI 8      // doubles of per-slot info: carries, window pointers, 1/(am_mid+eps), rho (prepare_slots)
+#ifndef MF_NT
 #define MF_NT 2      // base Gramian tiles per wave and pass, each with its three weights (9 accumulators of 8 VGPRs)
+#endif
 
 struct MfScratch {
   double* Q;   // Npad * nmax   bridged frequency windows
@@ -235,8 +237,8 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
           xr[cneg] = ru1 * (cu * pr - su * pi);    xi[cneg] = ru1 * (cu * pi + su * pr);
         }
 #endif
-        if (tid < TSf) {   // weights, DC and signal columns: one thread per chunk row
-          const int row = tid, el = row >> 1, d = d0 + el;
+        if (tid >= nt - TSf) {   // weights, DC and signal columns: one thread per chunk row (the last wave has the fewest build items)
+          const int row = tid - (nt - TSf), el = row >> 1, d = d0 + el;
           const int t = (row & 1) ? (mid + d) : (mid - d - 1);
           double w0 = 0.0, sv = 0.0;
           if (d <= mid && t >= 0) {
