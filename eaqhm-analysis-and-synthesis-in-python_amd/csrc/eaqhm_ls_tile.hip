@@ -185,7 +185,6 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           const double fu1 = fb[mid - dc], fv = fb[mid + dc];
           const double au = ab[(mid - dc - 1 >= 0) ? (mid - dc - 1) : 0], au1 = ab[mid - dc];
           const double av = ab[mid + dc], av1 = ab[(mid + dc + 1 < N) ? (mid + dc + 1) : (N - 1)];
-          __builtin_amdgcn_sched_barrier(0);   // all six requests in flight before anything waits on one
           // F(v) - F(mid) = sum of fm over (mid, v];  F(u) - F(mid) = -sum over [u+1, mid]
           const double xu = act ? fu1 : 0.0, xv = (act && d >= 1) ? fv : 0.0;
           const double qv = cj[0] + scan16(xv), qu = -(cj[1] + scan16(xu));
