@@ -275,19 +275,31 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
             }
             const double w0 = wrow[4 * ks], w1v = wrow[32 + 4 * ks], w2 = wrow[64 + 4 * ks];
             rb += 4 * ldx;
+            // all weighted operands first, then the MFMAs back to back: with a multiply in front of every MFMA a wave
+            // issues one only every ~186 cycles (93 per SIMD with its two waves) instead of every ~141
+            double sA[MF_NT], bRw[MF_NT][3], bIw[MF_NT][3], dw[MF_NT][3];
 #pragma unroll
             for (int sl = 0; sl < MF_NT; ++sl) {
-              if (!live[sl]) continue;
-              const double sA = aR[sl] + aI[sl];
+              sA[sl] = aR[sl] + aI[sl];
 #pragma unroll
               for (int w = 0; w < 3; ++w) {
                 const double wv = (w == 0) ? w0 : (w == 1) ? w1v : w2;
-                const double bRw = wv * bR[sl], bIw = wv * bI[sl];
-                P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[sl], bRw, P1[sl][w], 0, 0, 0);
-                P2[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[sl], bIw, P2[sl][w], 0, 0, 0);
-                P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA, bIw - bRw, P3[sl][w], 0, 0, 0);
+                bRw[sl][w] = wv * bR[sl]; bIw[sl][w] = wv * bI[sl];
+                dw[sl][w] = bIw[sl][w] - bRw[sl][w];
               }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < MF_NT; ++sl) {
+              if (!live[sl]) continue;
+#pragma unroll
+              for (int w = 0; w < 3; ++w) {
+                P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[sl], bRw[sl][w], P1[sl][w], 0, 0, 0);
+                P2[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[sl], bIw[sl][w], P2[sl][w], 0, 0, 0);
+                P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[sl], dw[sl][w], P3[sl][w], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
 #endif
