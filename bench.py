@@ -9,7 +9,13 @@ itself, as fresh child processes, before anything touches a GPU; rank 0 prints t
 
 A "step" is one complete run of the adaptation loop (functions.py:163-402) over the workload: adaptation
 0..maxAdpt or until the reference's stop rule fires.  Inputs (signal, pitch grid, frame tables) are resident in HBM
-before the timed region; result packing into Python structs is outside it.
+before the timed region; result packing into Python structs is outside it — what lies outside is
+timed once and reported next to the metric in `host_stages_s` (SWIPE', VUV + frame plan, upload, collecting the final
+arrays, packing the Deterministic structs) together with the end-to-end rate a caller of eaQHMAnalysisAndSynthesis sees.
+
+`roofline.frac` is the rate of the adaptation >= 1 launches (the kernel that executes the complex algorithm F(N, Kc)
+counts); the figure over all launches, which credits adaptation 0 with flops its closed-form real algorithm does not
+execute, is kept as `frac_all_launches_F_credit`.
 
 Workloads (BASELINE.json configs):
     synth16k_60s  (default) synthetic 60 s speech @16 kHz, `female`, maxAdpt=5 — configs[3], the workload
@@ -81,9 +87,71 @@ def load_workload(workload):
     return fs, s, grid, frames, fstep
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): what a profile must have been taken with to
+    describe the library this bench runs (tools/summarize_pmc.py stamps the same hash into pmc_hbm_traffic.json)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "eaqhm-analysis-and-synthesis-in-python_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) +
+                     glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def reference_srer(workload):
+    """SRER list of the REFERENCE for this workload where one exists (fixtures made by tests/golden/make_golden.py, which
+    imports the reference in the build container; sa19x10: BASELINE.md)."""
+    if workload == "synth16k_60s":
+        return [float(v) for v in np.load(os.path.join(GOLDEN, "synth16k_60s_adpt5.npz"))["SRER"]], \
+            "tests/golden/synth16k_60s_adpt5.npz (the reference itself on this workload, maxAdpt=5)"
+    if workload == "sa19":
+        return [float(v) for v in np.load(os.path.join(GOLDEN, "sa19_female_default.npz"))["SRER"]], \
+            "tests/golden/sa19_female_default.npz (= the reference's README screenshot)"
+    if workload == "sa19x10":
+        return [17.866028549428748, 24.213570062975556, 23.958838476216723], "BASELINE.md (reference run of the survey)"
+    return None, None
+
+
+def host_stages(workload, eng, plan, s, fs):
+    """What SURVEY §8d keeps outside the metric, timed once on this host: SWIPE' on the workload's signal, VUV + frame
+    plan, upload (engine construction), collecting the final arrays, packing the result structs (functions.py:86-146,
+    :404-411)."""
+    import torch
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.functions import pack_results
+    from eaqhm_amd.swipe import swipep
+    out = {}
+    t0 = time.perf_counter()
+    track = swipep(s, fs, [160, 300])
+    out["swipe"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan2 = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    out["vuv_and_plan"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng2 = DeviceAnalysis(s, s, plan2, 160, 0, device_index=eng.ctx.device.index)
+    torch.cuda.synchronize()
+    out["upload"] = time.perf_counter() - t0
+    del eng2
+    t0 = time.perf_counter()
+    fin = eng.final_arrays()
+    out["final_arrays"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    det = pack_results(plan, fin)
+    out["pack_results"] = time.perf_counter() - t0
+    out["structs"] = len(det)
+    return out
+
+
 def cpu_baseline(workload):
     """The oracle (NumPy port of the reference's path) on a bounded excerpt of the same workload, on this host's
-    cores: once with one BLAS thread and once with all the cores this process may use."""
+    cores: once with one BLAS thread and once with the GPU box's CPU share per GPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import eaqhm_oracle as O
     from threadpoolctl import threadpool_limits
@@ -111,6 +179,10 @@ def cpu_baseline(workload):
     best = max(runs, key=lambda k: runs[k][0])
     return {"value": runs[best][0], "unit": "frames/s", "cores": best, "kind": "port",
             "frames_per_s_1_thread": runs[1][0], "frames_per_s_%d_threads" % cores: runs[cores][0], "host_cores": host,
+            "threads_tried": [1, cores],
+            "threads_note": "SURVEY 8d asks for 1 thread and all cores; all %d host cores were measured in round 2 at 47 "
+                            "frames/s (the LS matrices are 100-200 wide: BLAS threads only contend), so the second leg "
+                            "uses the box's per-GPU CPU share (%d)" % (host, cores),
             "sample": "%s (%d LS frames; %.1f s at 1 BLAS thread, %.1f s at %d), oracle/eaqhm_oracle.py"
                       % (sample, runs[1][2]["n_ls_frames"], runs[1][1], runs[cores][1], cores),
             "srer_db": [float(v) for v in runs[best][2]["SRER"]]}
@@ -118,20 +190,45 @@ def cpu_baseline(workload):
 
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (nothing in this process
-    has touched a GPU yet) and pass rank 0's JSON line through."""
+    has touched a GPU yet) and pass rank 0's JSON line through.  The children are polled: the first one that fails takes
+    its siblings down (they would otherwise sit in a collective until the RCCL timeout) and its exit code is returned.
+    A rendezvous port that turns out to be taken (bind-then-close is a race against other jobs) gets two more tries."""
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    rc = 1
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None))
+        rc, err0 = 0, b""
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code
+        if rc != 0:
+            for p in live:               # exact PIDs this process started
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        err0 = procs[0].stderr.read() if procs[0].stderr else b""
+        sys.stderr.buffer.write(err0)
+        if rc == 0 or b"EADDRINUSE" not in err0 and b"Address already in use" not in err0:
+            return rc
     return rc
 
 
@@ -143,6 +240,7 @@ def main():
     ap.add_argument("--max-adpt", type=int, default=5)
     ap.add_argument("--workload", default="synth16k_60s", choices=WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-stages", action="store_true", help="skip the one-off timing of SWIPE' / VUV / packing")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -258,14 +356,26 @@ def main():
     ms0 = [t for a, t in zip(ls_a, ls_ms) if a == 0]
     # HBM traffic of that kernel: not measurable from inside this process; taken from the committed rocprofv3 PMC
     # passes of this same command and workload (profiles/r02_<workload>/pmc_hbm_traffic.json), N = 1 only
+    # (the PMC passes of tools/profile_round.sh; used only if they were taken with exactly these kernel sources)
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_%s" % args.workload, "pmc_hbm_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_%s" % args.workload, "pmc_hbm_traffic.json")
+    src = source_hash()
     if world == 1 and os.path.exists(pmc):
         j = json.load(open(pmc))
-        traffic = j.get(kernel, {}).get("hbm_bytes_per_launch_fetch_doubled")
-        traffic_src = {"file": os.path.relpath(pmc, ROOT), "git_head": j.get("git_head")}
+        traffic_src = {"file": os.path.relpath(pmc, ROOT), "profile_source_hash": j.get("source_hash"),
+                       "tree_source_hash": src}
+        if j.get("source_hash") == src:
+            traffic = j.get(kernel, {}).get("hbm_bytes_per_launch_fetch_doubled")
+        else:
+            traffic_src["stale"] = "kernel sources changed since the counter passes: traffic withheld"
+    achieved_all = achieved
+    if frac_ge1 is not None:
+        achieved = frac_ge1 * PEAK_FP64_TFLOPS
     roofline = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
+                "frac_definition": "algorithmic flops F(N,Kc) of the adaptation >= 1 launches / their HIP-event time "
+                                   "(rank 0); all launches incl. the cheaper closed-form adaptation 0: frac_all_launches_F_credit",
+                "frac_all_launches_F_credit": achieved_all / PEAK_FP64_TFLOPS, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
@@ -274,6 +384,7 @@ def main():
                 "launch_ms_mean": float(np.mean(ls_ms)) if ls_ms else None,
                 "launch_ms_adaptation0": float(np.mean(ms0)) if ms0 else None,
                 "frac_adaptation_ge1_launches": frac_ge1,
+                "source_hash": src,
                 "launches_timed": len(ls_ms),
                 "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None,
                 "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None,
@@ -293,6 +404,21 @@ def main():
                       "parallelism": "instants sharded x%d by LS cost; boundary records all-gathered per adaptation"
                                      % world},
            "final_srer_db": max(srer), "srer_db": srer, "roofline": roofline}
+    ref, ref_src = reference_srer(args.workload)
+    if ref is not None and args.max_adpt == 5:
+        out["srer_ref_db"] = ref
+        out["srer_ref_source"] = ref_src
+        out["final_srer_ref_db"] = max(ref)
+        out["srer_abs_diff_db"] = ([abs(a - b) for a, b in zip(srer, ref)] if len(ref) == len(srer) else None)
+        out["final_srer_abs_diff_db"] = abs(max(srer) - max(ref))
+    if rank == 0 and world == 1 and not args.no_host_stages:
+        hs = host_stages(args.workload, eng, plan, s, fs)
+        loop_s = dt / args.steps
+        out["host_stages_s"] = hs
+        total = hs["swipe"] + hs["vuv_and_plan"] + hs["upload"] + loop_s + hs["final_arrays"] + hs["pack_results"]
+        out["end_to_end"] = {"seconds": total, "frames_per_sec": frames_total / args.steps / total,
+                             "note": "one call of eaQHMAnalysisAndSynthesis on this file: SWIPE' + VUV/plan + upload + "
+                                     "adaptation loop + final arrays + struct packing (wav decoding excluded)"}
     if rehearsal:
         out["rehearsal"] = "all ranks on one GPU, collectives staged through the host: code-path check only"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,7 @@
 
 #include "../../include/eaqhm_hip.h"
 
-#define EAQHM_ABI_VERSION 2
+#define EAQHM_ABI_VERSION 3
 
 struct eaqhm_ctx {
   int device = 0;
@@ -20,7 +20,8 @@ struct eaqhm_ctx {
   int dbg_keep = 0;    // 1: in-kernel phase stamps on, accumulated across launches (diagnostics only)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  int* faults = nullptr;   // device counter: LS systems whose Cholesky pivot collapsed (singular normal matrix)
+  int* faults = nullptr;   // device counters: [0] LS systems whose Cholesky broke down (singular normal matrix),
+                           // [1] diagonal pipelines whose hand-shake timed out (eaqhm_ls_chol.h: spin_until)
   char err[512] = {0};
 
   int fail(int code, const char* msg) {

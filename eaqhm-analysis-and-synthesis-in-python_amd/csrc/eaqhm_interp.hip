@@ -137,8 +137,27 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_spline_edge_kernel(const
 struct EvalArgs {
   const double* records; const unsigned char* code; const double* mom;
   int No_ti; int Kmax; int step; double fs; long long L; long long t_lo; long long t_hi; long long s_lo; long long s_hi;
-  const double* target; double* am_out; double* fm_out; double* ph_knot; double* s_hat; double* partials;
+  // am_out / fm_out: biased by -track_t0, rows of Lt samples (only samples [t_lo, t_hi) are written); NULL: no track
+  // output.  s_hat NULL: no synthesis, no phase rows, no error sums (a pass that only regenerates tracks).
+  const double* target; double* am_out; double* fm_out; long long Lt; double* ph_knot; double* s_hat; long long* partials;
 };
+
+// ---- error sums that do not depend on how the samples are grouped -------------------------------------------------
+// SRER (functions.py:388) needs sum d and sum d^2 over the whole file, d = target - s_hat.  They are collected per
+// block, per rank and (long files) per time block; a floating-point sum would make the last digits of the SRER — and
+// with them the stop rule `SRER[a] <= SRER[a-1]` — depend on that grouping.  So every sample is turned into fixed
+// point, three signed 64-bit limbs in base 2^32 (d * 2^60 and d^2 * 2^64, truncated: 2^-60 / 2^-64 absolute), and the
+// limbs are added as integers: exact, associative, identical for every block size, world size and streaming block.
+// |d| < 2^20 is required (anything larger, and NaN / Inf, is counted in limb 6 and reported by the host).
+#define ES_LIMBS 8   // {d: l0, l1, l2,  d^2: l0, l1, l2,  non-finite or huge samples, -}
+__device__ inline void fixed_limbs(double x, long long& l0, long long& l1, long long& l2) {
+  // x already scaled by a power of two (exact); |x| < 2^104
+  const double h2 = trunc(x * 0x1p-64);
+  const double r1 = x - h2 * 0x1p64;          // exact: the low bits of x
+  const double h1 = trunc(r1 * 0x1p-32);
+  const double r0 = r1 - h1 * 0x1p32;         // exact
+  l2 = (long long)h2; l1 = (long long)h1; l0 = (long long)trunc(r0);
+}
 
 // Rows [r0, r1] of records / code / mom staged in LDS by the block (eaqhm_eval_kernel); anything outside (only the
 // padded <4-knot case reaches back to rows 0..3) is read from memory.
@@ -358,18 +377,21 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
             }
             if (prev) fnext = A.fs / (2.0 * M_PI) * unwrap_diff(phv - pDm1);
           }
-          A.ph_knot[(size_t)i * K + k] = phv;
+          if (A.s_hat) A.ph_knot[(size_t)i * K + k] = phv;
         } else {
-          A.ph_knot[(size_t)i * K + k] = 0.0;
+          if (A.s_hat) A.ph_knot[(size_t)i * K + k] = 0.0;
         }
       }
-      A.am_out[(size_t)k * A.L + t] = amv;
-      A.fm_out[(size_t)k * A.L + t] = fnext;
-      X1[(size_t)k * TP + s] = (amv != 0.0) ? amv * cos(phv) : 0.0;   // same thread read this cell above
+      if (A.am_out) {
+        A.am_out[(size_t)k * A.Lt + t] = amv;
+        A.fm_out[(size_t)k * A.Lt + t] = fnext;
+      }
+      if (A.s_hat) X1[(size_t)k * TP + s] = (amv != 0.0) ? amv * cos(phv) : 0.0;   // same thread read this cell above
     }
   }
+  if (!A.s_hat) return;   // (uniform over the grid: a track-only pass)
   __syncthreads();
-  double dsum = 0.0, dsq = 0.0;
+  long long e[ES_LIMBS - 1] = {0, 0, 0, 0, 0, 0, 0};
   if (tid < TBS && live) {
     double synth = 0.0;
 #pragma unroll 8
@@ -377,58 +399,62 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
     // a0: not-a-knot spline through every instant, extrapolated past the last one (functions.py:340)
     int ia = i;
     if (ia > A.No_ti - 2) ia = A.No_ti - 2;
-    const int ld = K + 1;
     const size_t RS = 3 * (size_t)K + 1;
     Slot S0{A, C, K};   // column K of mom = the a0 spline; its knots are the last record column
-    (void)ld;
     double a0v = spline_piece(S0.recv(ia, (int)RS - 1), S0.recv(ia + 1, (int)RS - 1), S0.mom(ia), S0.mom(ia + 1),
                               (double)(t - (long long)ia * D), (double)D);
     const double sh = a0v + 2.0 * synth;
     A.s_hat[t] = sh;
     if (t >= A.s_lo && t < A.s_hi) {
       const double d = A.target[t] - sh;
-      dsum = d; dsq = d * d;
+      if (fabs(d) < 0x1p20) {   // (false for NaN)
+        fixed_limbs(d * 0x1p60, e[0], e[1], e[2]);
+        fixed_limbs((d * d) * 0x1p64, e[3], e[4], e[5]);
+      } else {
+        e[6] = 1;
+      }
     }
   }
   if (tid < 64) {   // TBS <= 64: the block's samples sit in the first wave
-    for (int o = 32; o > 0; o >>= 1) {
-      dsum += __shfl_xor(dsum, o);
-      dsq += __shfl_xor(dsq, o);
-    }
-    if (tid == 0) {
-      A.partials[2 * (size_t)blockIdx.x] = dsum;
-      A.partials[2 * (size_t)blockIdx.x + 1] = dsq;
+#pragma unroll
+    for (int q = 0; q < ES_LIMBS - 1; ++q) {
+      for (int o = 32; o > 0; o >>= 1) e[q] += __shfl_xor(e[q], o);
+      if (tid == 0) A.partials[ES_LIMBS * (size_t)blockIdx.x + q] = e[q];
     }
   }
 }
 
-// partials of `group` consecutive blocks are added first, so that the result does not depend on the block size
-extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const double* partials, long long nblocks, int group,
-                                                                    double n, double std_det, double* sums_out,
-                                                                    int* faults) {
-  __shared__ double red[8];
-  double a = 0, b = 0;
-  const long long ngroups = (nblocks + group - 1) / group;
-  for (long long q = threadIdx.x; q < ngroups; q += blockDim.x) {
-    double pa = 0, pb = 0;
-    for (int w = 0; w < group; ++w) {
-      const long long x = q * group + w;
-      if (x < nblocks) { pa += partials[2 * x]; pb += partials[2 * x + 1]; }
-    }
-    a += pa; b += pb;
+// Adds the blocks' limbs (integers: any order gives the same result), carries them into two 128-bit totals and leaves
+//   sums_out[0..3]  sum d, sum d^2, n, SRER in dB — doubles, a convenience for C callers; the Python host derives the
+//                   SRER itself from the limbs (one formula for every world size and block count)
+//   sums_out[4..5]  LS faults / stalled diagonal pipelines since the last read (both counters are cleared)
+//   sums_out[8..15] the limbs as int64 bit patterns: what ranks and time blocks add up
+extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const long long* partials, long long nblocks, double n,
+                                                                    double std_det, double* sums_out, int* faults) {
+  __shared__ long long red[4][ES_LIMBS];
+  long long e[ES_LIMBS - 1] = {0, 0, 0, 0, 0, 0, 0};
+  for (long long b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+    for (int q = 0; q < ES_LIMBS - 1; ++q) e[q] += partials[ES_LIMBS * b + q];
+#pragma unroll
+  for (int q = 0; q < ES_LIMBS - 1; ++q) {
+    for (int o = 32; o > 0; o >>= 1) e[q] += __shfl_xor(e[q], o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = e[q];
   }
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = a; red[2 * (threadIdx.x >> 6) + 1] = b; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a = red[0] + red[2] + red[4] + red[6];
-    b = red[1] + red[3] + red[5] + red[7];
-    double mean = a / n;
-    double var = b / n - mean * mean;
+    long long* lim = (long long*)(sums_out + 8);
+    for (int q = 0; q < ES_LIMBS - 1; ++q) { e[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q]; lim[q] = e[q]; }
+    lim[ES_LIMBS - 1] = 0;
+    const double a = ((double)e[2] * 0x1p64 + (double)e[1] * 0x1p32 + (double)e[0]) * 0x1p-60;
+    const double b = ((double)e[5] * 0x1p64 + (double)e[4] * 0x1p32 + (double)e[3]) * 0x1p-64;
+    const double mean = a / n;
+    const double var = b / n - mean * mean;
     sums_out[0] = a; sums_out[1] = b; sums_out[2] = n;
-    sums_out[3] = 20.0 * log10(std_det / sqrt(var));
-    sums_out[4] = (double)*faults;   // LS systems with a collapsed pivot in this adaptation (eaqhm_ls_faults)
-    *faults = 0;
+    sums_out[3] = e[6] ? __builtin_nan("") : 20.0 * log10(std_det / sqrt(var));
+    sums_out[4] = (double)faults[0];   // LS systems whose factorisation broke down in this adaptation (eaqhm_ls_faults)
+    sums_out[5] = (double)faults[1];   // diagonal pipelines that timed out (a bug of the library if ever nonzero)
+    faults[0] = 0; faults[1] = 0;
   }
 }
 
@@ -516,22 +542,28 @@ static int eval_block_samples(int Kmax, int step, size_t* lds_bytes, int* nk, in
 
 extern "C" int64_t eaqhm_eval_partials_len(int64_t t_lo, int64_t t_hi, int32_t step) {
   (void)step;
-  if (t_hi <= t_lo) return 2;
-  return 2 * ((t_hi - t_lo + 15) / 16);   // one pair per block of >= 16 samples
+  if (t_hi <= t_lo) return ES_LIMBS;
+  return ES_LIMBS * ((t_hi - t_lo + 15) / 16);   // eight 8-byte words per block of >= 16 samples
 }
 
 extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uint8_t* code,
                                 const double* mom, int32_t No_ti, int32_t Kmax, int32_t step, double fs, int64_t L,
                                 int64_t t_lo, int64_t t_hi, int64_t s_lo, int64_t s_hi, const double* target,
-                                double std_det, double* am_out,
-                                double* fm_out, double* ph_knot, double* s_hat, double* partials, double* sums_out) {
+                                double std_det, double* am_out, double* fm_out, int64_t track_t0, int64_t track_len,
+                                double* ph_knot, double* s_hat, double* partials, double* sums_out) {
   if (!ctx) return EAQHM_EINVAL;
-  if (!records || !code || !mom || !target || !am_out || !fm_out || !ph_knot || !s_hat || !partials ||
-      !sums_out || No_ti < 4 || Kmax <= 0 || step <= 0 || fs <= 0 || L <= 0 || t_lo < 0 || t_hi > L || t_lo >= t_hi || s_lo < t_lo || s_hi > t_hi || s_lo >= s_hi)
+  const bool tracks = am_out != nullptr, synth = s_hat != nullptr;
+  if (!records || !code || !mom || (!tracks && !synth) || (tracks && !fm_out) || No_ti < 4 || Kmax <= 0 || step <= 0 ||
+      fs <= 0 || L <= 0 || t_lo < 0 || t_hi > L || t_lo >= t_hi)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: bad argument");
+  if (synth && (!target || !ph_knot || !partials || !sums_out || s_lo < t_lo || s_hi > t_hi || s_lo >= s_hi))
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: bad argument (synthesis outputs / error range)");
+  if (tracks && (track_t0 < 0 || track_len <= 0 || t_lo < track_t0 || t_hi > track_t0 + track_len))
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: [t_lo, t_hi) outside the track window");
   if ((int64_t)(No_ti - 1) * step >= L) return ctx->fail(EAQHM_EINVAL, "eaqhm_eval_synth: instants beyond the signal");
   EvalArgs A{records, code, mom, No_ti, Kmax, step, fs, (long long)L, (long long)t_lo, (long long)t_hi,
-             (long long)s_lo, (long long)s_hi, target, am_out, fm_out, ph_knot, s_hat, partials};
+             (long long)s_lo, (long long)s_hi, target, tracks ? am_out - track_t0 : nullptr,
+             tracks ? fm_out - track_t0 : nullptr, (long long)track_len, ph_knot, s_hat, (long long*)partials};
   size_t lds_bytes = 0;
   int NK = 0, NR = 0;
   const int TBS = eval_block_samples(Kmax, step, &lds_bytes, &NK, &NR);
@@ -540,7 +572,8 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK, NR);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, nblocks, 256 / TBS,
+  if (!synth) return EAQHM_OK;
+  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, (const long long*)partials, nblocks,
                      (double)(s_hi - s_lo), std_det, sums_out, ctx->faults);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;

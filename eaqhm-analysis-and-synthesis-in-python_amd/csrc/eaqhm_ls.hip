@@ -20,7 +20,7 @@ namespace eaqhm {
 int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb);  // eaqhm_ls_mfma.hip
 size_t ls_mfma_scratch_stride(int nmax, int Nmax, int Kcmax);
 int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid);              // eaqhm_ls_tile.hip
-int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A);                    // eaqhm_ls_tile.hip (classes, zero counts)
+int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A, long long track_t0);                    // eaqhm_ls_tile.hip (classes, zero counts)
 size_t ls_tile_scratch_stride(int nmax, int Nmax);
 bool ls_tile_applicable(int Kcmax, int Nmax);
 
@@ -72,7 +72,7 @@ __device__ void gram_to_system(const double* __restrict__ Xre, const double* __r
 // ------------------------------------------------------------------------------------------------
 // adaptation >= 1 frame set-up (functions.py:202-213): active slots + empty-row seeding flags
 // One wave per frame: lanes test 64 slots at a time, the ballot gives count and compacted positions.
-extern "C" __global__ void __launch_bounds__(256) eaqhm_frame_prep_kernel(const double* fm_cur, long long L, int Kmax,
+extern "C" __global__ void __launch_bounds__(256) eaqhm_frame_prep_kernel(const double* fm_cur /* biased by -track_t0 */, long long L /* row stride */, int Kmax,
                                                                           const int* frame_c, int n_frames, int* ncol,
                                                                           int* cols, unsigned char* seeded, int* any_seed) {
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -168,23 +168,25 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_explicit_kernel(LsExp
 // C ABI
 using namespace eaqhm;
 
-extern "C" int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int32_t Kmax,
-                                const int32_t* frame_c, int32_t n_frames, int32_t* ncol, int32_t* cols,
+extern "C" int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int64_t track_t0, int64_t track_len,
+                                int32_t Kmax, const int32_t* frame_c, int32_t n_frames, int32_t* ncol, int32_t* cols,
                                 uint8_t* seeded, int32_t* any_seed) {
   if (!ctx) return EAQHM_EINVAL;
-  if (!fm_cur || !frame_c || !ncol || !cols || !seeded || !any_seed || L <= 0 || Kmax <= 0 || n_frames < 0)
+  if (!fm_cur || !frame_c || !ncol || !cols || !seeded || !any_seed || L <= 0 || Kmax <= 0 || n_frames < 0 ||
+      track_t0 < 0 || track_len <= 0 || track_t0 + track_len > L)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_frame_prep: bad argument");
   HIP_TRY(ctx, hipMemsetAsync(seeded, 0, (size_t)L, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(any_seed, 0, sizeof(int32_t), ctx->stream));
   if (n_frames == 0) return EAQHM_OK;
-  hipLaunchKernelGGL(eaqhm_frame_prep_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, ctx->stream, fm_cur,
-                     (long long)L, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed);
+  hipLaunchKernelGGL(eaqhm_frame_prep_kernel, dim3((n_frames + 3) / 4), dim3(256), 0, ctx->stream, fm_cur - track_t0,
+                     (long long)track_len, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }
 
 extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int64_t L, double fs,
-                              const double* am_cur, const double* fm_cur, int32_t Kmax, const int32_t* frame_inst,
+                              const double* am_cur, const double* fm_cur, int64_t track_t0, int64_t track_len,
+                              int32_t Kmax, const int32_t* frame_inst,
                               const int32_t* frame_c, const int32_t* frame_wl, const double* frame_f0,
                               const int32_t* frame_K, const int32_t* ncol, const int32_t* cols,
                               const uint8_t* seeded, const int32_t* any_seed, int32_t n_frames, int32_t wl_max,
@@ -198,12 +200,18 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   if (mode == 0 && (!frame_f0 || !frame_K)) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: mode 0 needs frame_f0/frame_K");
   if (mode == 1 && (!am_cur || !fm_cur || !ncol || !cols || !seeded || !any_seed))
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: mode 1 needs tracks and eaqhm_frame_prep outputs");
+  if (mode == 1 && (track_t0 < 0 || track_len <= 0 || track_t0 + track_len > L))
+    return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: track window outside the signal");
+  if (mode == 0) { track_t0 = 0; track_len = L; }
   if ((raw_amp == nullptr) != (raw_slope == nullptr)) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: raw_amp/raw_slope");
   if (n_frames == 0) return EAQHM_OK;
   if (wl_max <= 0) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: wl_max must be positive");
   const int nmax = Kmax, Nmax = 2 * wl_max + 1, Kcmax = 2 * Kmax + 1;
   LsArgs B;
-  B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.am_cur = am_cur; B.fm_cur = fm_cur; B.Kmax = Kmax;
+  B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.Kmax = Kmax;
+  // tracks (and the zero counts below) biased by the window's first sample: the kernels index with absolute samples.
+  // Every frame window must lie inside [track_t0, track_t0 + track_len): the caller's contract (checked on the host side).
+  B.am_cur = am_cur ? am_cur - track_t0 : nullptr; B.fm_cur = fm_cur ? fm_cur - track_t0 : nullptr; B.Lt = track_len;
   B.frame_inst = frame_inst; B.frame_c = frame_c; B.frame_wl = frame_wl; B.frame_f0 = frame_f0; B.frame_K = frame_K;
   B.ncol = ncol; B.cols = cols; B.seeded = seeded; B.any_seed = any_seed; B.n_frames = n_frames; B.a_iter = a_iter;
   B.f0_stale = f0_stale; B.f0min = f0min; B.records = records; B.raw_amp = raw_amp; B.raw_slope = raw_slope;
@@ -212,13 +220,13 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   const size_t st_m = ls_mfma_scratch_stride(nmax, Nmax, Kcmax), st_t = ls_tile_scratch_stride(nmax, Nmax);
   const size_t frame_bytes = (st_m > st_t ? st_m : st_t) * grid * sizeof(double);
   const int zchunks = (int)((L + 1023) >> 10);
-  const size_t zloc_bytes = (((size_t)Kmax * L * sizeof(unsigned short)) + 255) & ~(size_t)255;
+  const size_t zloc_bytes = (mode == 1) ? ((((size_t)Kmax * track_len * sizeof(unsigned short)) + 255) & ~(size_t)255) : 256;
   const size_t ztot_bytes = (((size_t)Kmax * zchunks * sizeof(int)) + 255) & ~(size_t)255;
   const size_t flag_bytes = zloc_bytes + ztot_bytes + (((size_t)zchunks + 255) & ~(size_t)255);
   const size_t cls_bytes = ((16 + (size_t)LS_NCLS * n_frames) * sizeof(int) + 255) & ~(size_t)255;
   int rc = ctx->reserve(frame_bytes + flag_bytes + cls_bytes + 256);
   if (rc) return rc;
-  B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes);
+  B.zloc = (const unsigned short*)((char*)ctx->scratch + frame_bytes) - track_t0;
   B.ztot = (const int*)((char*)ctx->scratch + frame_bytes + zloc_bytes);
   B.zchunks = zchunks;
   B.zflag = (unsigned char*)ctx->scratch + frame_bytes + zloc_bytes + ztot_bytes;
@@ -234,7 +242,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
   B.scratch = (double*)ctx->scratch;
   int min_nb = 0;
-  rc = launch_ls_prepass(ctx, B);
+  rc = launch_ls_prepass(ctx, B, track_t0);
   if (rc) return rc;
   if (tile_path) {   // small frames: everything in registers/LDS; the rest falls through
     B.scratch_stride = st_t; B.work_counter = counters + 2;

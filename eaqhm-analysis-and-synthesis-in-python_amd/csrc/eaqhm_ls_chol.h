@@ -26,10 +26,9 @@ __device__ inline void diag_init(double* Z, int tid) {
 
 // Singular systems: position q of the tile is a real unknown when q < nvalid (the others are the right-hand-side
 // position or identity padding).  dref[q] is the ORIGINAL diagonal entry of the system at that position; a pivot
-// (the squared diagonal of L) that has collapsed to <= PIVOT_TOL of it means the column is a combination of earlier
-// ones — the reference's inv() raises LinAlgError there (functions.py:465, :530).  One thread watches the pivots
-// and counts the frame in *fault (eaqhm_ls_faults).
-#define PIVOT_TOL 1e-12
+// (the squared diagonal of L) that is <= PIVOT_TOL of it (eaqhm_ls_common.h) is a breakdown of the factorisation — the
+// column is, to rounding, a combination of earlier ones; the reference's inv() raises LinAlgError on the exact form of
+// that (functions.py:465, :530).  One thread watches the pivots and counts the frame in *fault (eaqhm_ls_faults).
 __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI, double* LdR, double* LdI, int tid,
                                  const double* dref, int nvalid, int* fault) {
   // 2x2 block pivots: seven elimination steps instead of fifteen.  With P = [[p, conj(q)], [q, r]] the pivot block
@@ -166,9 +165,9 @@ __device__ inline double rsqrt_nr(double x) {
   return y;
 }
 
-// Bounded wait on the pipeline's step counter: every wave reaches an exit even if the protocol were broken (the frame
-// is then counted DIAG_STUCK times in the fault counter and the host raises).
-#define DIAG_STUCK (1 << 20)
+// Bounded wait on the pipeline's step counter: every wave reaches an exit even if the protocol were broken; the frame
+// is then counted in fault[1] (a counter of its own: a stalled hand-shake is a bug of this library, not a singular
+// matrix) and the host raises RuntimeError.
 __device__ inline bool spin_until(int* flag, int target) {
   for (int spins = 0; spins < (1 << 16); ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
@@ -277,7 +276,7 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
   // ---- every pivot block's own Cholesky factor [[l11, 0], [l21, l22]] at once (lane b <-> block b), the collapsed-
   //      pivot check, and the rows of W:  W[j] = Z[j] / l11,  W[j+1] = (Z[j+1] - l21 W[j]) / l22
   if (!spin_until(flag, flag_base + 8)) stuck = 1;
-  if (stuck && lane == 0) atomicAdd(fault, DIAG_STUCK);
+  if (stuck && lane == 0) atomicAdd(fault + 1, 1);
   {
     const int b = lane & 7, j = 2 * b;
     const double* rows = post + b * 64;
@@ -394,7 +393,7 @@ __device__ __attribute__((always_inline)) inline void diag_Zr(const double* post
     Z = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, -res, Z, 0, 0, 0);
   }
   if (!spin_until(flag, flag_base + 8)) stuck = 1;
-  if (stuck && lane == 0) atomicAdd(fault, DIAG_STUCK);
+  if (stuck && lane == 0) atomicAdd(fault + 1, 1);
   {
     const int b = lane & 7, j = 2 * b;
     const double* rows = post + b * 32;

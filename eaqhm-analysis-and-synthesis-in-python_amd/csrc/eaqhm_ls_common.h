@@ -7,13 +7,24 @@
 
 namespace eaqhm {
 
+// Singular systems.  The reference solves with inv() (functions.py:465, :530), which raises only on an EXACTLY zero LU
+// pivot and otherwise returns whatever the ill-conditioned system gives.  The kernels factorise by Cholesky; what
+// corresponds to the exact zero is a breakdown of the factorisation: a pivot (the squared diagonal of L) that is not
+// positive or is lost in the rounding of its own update, i.e. <= PIVOT_TOL = order * eps (order <= ~1200) of the ORIGINAL
+// diagonal entry.  Exactly duplicated basis columns land there (their pivot is d - d(1 +- a few eps)); systems that are
+// merely ill-conditioned (scaled cond up to ~1e12) do not, and are solved like the reference solves them.
+#define PIVOT_TOL 2.5e-13
+
 #define LS_NCLS 7
 #define LS_BIG_CLASS (LS_NCLS - 1)
 
 struct LsArgs {
   int mode;  // 0: adaptation 0 (stationary harmonics), 1: adaptation >= 1 (tracks)
   const double* s; long long L; double fs;
-  const double* am_cur; const double* fm_cur; int Kmax;
+  // dense tracks of the previous adaptation: rows of Lt samples that hold samples [t0, t0 + Lt) of the file.  The two
+  // pointers (and zloc) are BIASED by -t0 on the host side of the C ABI, so that row k, absolute sample t is at
+  // [k * Lt + t] — the kernels index with absolute sample numbers whatever window of the file is resident.
+  const double* am_cur; const double* fm_cur; long long Lt; int Kmax;
   const int* frame_inst; const int* frame_c; const int* frame_wl; const double* frame_f0; const int* frame_K;
   const int* ncol; const int* cols; const unsigned char* seeded; const int* any_seed;
   int n_frames; int a_iter; double f0_stale; double f0min;
@@ -28,7 +39,7 @@ struct LsArgs {
   // Classes 0-5 are the register budgets of eaqhm_ls_tile_kernel, class LS_BIG_CLASS is left to eaqhm_ls_mfma_kernel.
   int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
-  int* fault;                 // device counter of singular systems (eaqhm_ctx::faults)
+  int* fault;                 // device counters (eaqhm_ctx::faults): [0] singular systems, [1] stalled diagonal pipelines
 };
 
 // wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
@@ -49,11 +60,11 @@ __device__ inline T* uni(T* p) {
 // in slot 0 to the frames at or after it, exactly like the sequential write of the reference
 __device__ inline double track_fm(const LsArgs& A, int k, long long t, int c, bool seeds) {
   if (seeds && k == 0 && t <= c && A.seeded[t]) return 140.0;
-  return A.fm_cur[(size_t)k * A.L + t];
+  return A.fm_cur[(size_t)k * A.Lt + t];
 }
 __device__ inline double track_am(const LsArgs& A, int k, long long t, int c, bool seeds) {
   if (seeds && k == 0 && t <= c && A.seeded[t]) return 10e-4;
-  return A.am_cur[(size_t)k * A.L + t];
+  return A.am_cur[(size_t)k * A.Lt + t];
 }
 
 // sin and cos of a double in one go with a small register footprint: 3-term Cody-Waite reduction by pi/2
@@ -215,7 +226,7 @@ __device__ inline void prepare_slots(const LsArgs& A, double* Qf, double* Af, in
   const int* ztot = uni(A.ztot);
   const double* fm_all = uni(A.fm_cur);
   const double* am_all = uni(A.am_cur);
-  const long long L = ((long long)uni((int)(A.L >> 32)) << 32) | (unsigned)uni((int)(A.L & 0xffffffffll));
+  const long long L = ((long long)uni((int)(A.Lt >> 32)) << 32) | (unsigned)uni((int)(A.Lt & 0xffffffffll));   // row stride of the tracks
   const int zchunks = uni(A.zchunks);
   const double w1 = uni(2.0 * M_PI / A.fs);
   auto centre = [&](int j, double fv, double av) {
@@ -334,7 +345,7 @@ __device__ inline void cholesky_solve(double* __restrict__ Lt, int M, int ldl, d
         ai -= li * cr - lr * ci;
       }
       if (i == j) {
-        if (!(ar > 1e-12 * Lt[oj])) { atomicAdd(fault, 1); ar = 1.0; }   // collapsed pivot: singular normal matrix
+        if (!(ar > PIVOT_TOL * Lt[oj])) { atomicAdd(fault, 1); ar = 1.0; }   // Cholesky breakdown: singular normal matrix
         double d = sqrt(ar);
         sh[0] = d;
         Lt[oj] = d; Lt[oj + 1] = 0.0;

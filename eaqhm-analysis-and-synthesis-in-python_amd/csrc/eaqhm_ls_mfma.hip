@@ -408,7 +408,8 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
   const size_t a0_bytes = a0_lds_doubles(MF_A0_M, 1, Kcmax + 1, MF_A0_NCH, ((A.Nmax >> 1) + 8) & ~7, (A.Nmax + 7) & ~7, Kcmax) * sizeof(double);
-  const int a0_onchip = (A.mode == 0 && a0_bytes <= 160 * 1024) ? 1 : 0;
+  // (159 KiB: the kernel also has a static __shared__ word, and dynamic + static must fit the 160 KiB of a workgroup)
+  const int a0_onchip = (A.mode == 0 && a0_bytes <= 159 * 1024) ? 1 : 0;
   if (a0_onchip) {
     // its frame cursor: a free slot of the class header / of the zeroed counter block (eaqhm_ls_batch)
     int* cursor = (min_nb > 0) ? (A.cls + 15) : (A.work_counter + 2);

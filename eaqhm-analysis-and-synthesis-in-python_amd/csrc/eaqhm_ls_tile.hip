@@ -532,8 +532,11 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArg
 
 // Zero counts of every frequency track, in chunks of 1024 samples (LsArgs::zloc / ztot): a frame then knows with two
 // look-ups per slot whether its window needs bridging, instead of scanning n windows of N samples.
-extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(const double* __restrict__ fm, long long L,
-                                                                              int zchunks, const unsigned char* __restrict__ zflag,
+// fm / zloc: biased by the first resident sample t_lo (LsArgs), rows of Lt samples; samples outside [t_lo, t_lo + Lt) are
+// not resident (no frame window of this launch reaches them) and count as nonzero.
+extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(const double* __restrict__ fm, long long Lt,
+                                                                              long long t_lo, int zchunks,
+                                                                              const unsigned char* __restrict__ zflag,
                                                                               unsigned short* __restrict__ zloc,
                                                                               int* __restrict__ ztot) {
   __shared__ int wsum[4];
@@ -543,7 +546,8 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(co
   int run = 0;
   for (int p = 0; p < 4; ++p) {
     const long long t = base + 256 * p + tid;
-    const bool z = (t < L) && (fm[(size_t)k * L + t] == 0.0);
+    const bool in = t >= t_lo && t < t_lo + Lt;
+    const bool z = in && (fm[(size_t)k * Lt + t] == 0.0);
     const unsigned long long m = __ballot(z);
     const int incl = __popcll(m & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
     if (lane == 0) wsum[wave] = __popcll(m);
@@ -551,7 +555,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(co
     int off = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { const int v = wsum[w]; tot += v; if (w < wave) off += v; }
-    if (t < L) zloc[(size_t)k * L + t] = (unsigned short)(run + off + incl);
+    if (in) zloc[(size_t)k * Lt + t] = (unsigned short)(run + off + incl);
     run += tot;
     __syncthreads();
   }
@@ -582,6 +586,9 @@ extern "C" __global__ void __launch_bounds__(TL_THREADS) eaqhm_ls_tile_kernel(Ls
 #undef RUN_CLASS
 }
 
+// dynamic LDS the kernel may ask for: it also has a static __shared__ word (the frame cursor), and dynamic + static must
+// fit the 160 KiB of a workgroup
+#define TL_LDS_LIMIT (159 * 1024)
 static size_t tl_usize_c() {
   return (size_t)4 * TL_NTMAX * TL_TILE + 2 * TL_TILE + 2 * DG_TILE + 2 * 16 * TL_NTMAX + 32;
 }
@@ -593,7 +600,7 @@ static size_t tl_lds_doubles(int Kcmax, int TS, int ldx_max) {
 
 // the tile variant needs its LDS budget (which grows with Kmax through the solution vector) to fit
 bool ls_tile_applicable(int Kcmax, int Nmax) {
-  return Nmax <= 64 * CI_NCH && tl_lds_doubles(Kcmax, 32, 16 * TL_NTMAX + 16) * sizeof(double) <= 160 * 1024;
+  return Nmax <= 64 * CI_NCH && tl_lds_doubles(Kcmax, 32, 16 * TL_NTMAX + 16) * sizeof(double) <= TL_LDS_LIMIT;
 }
 
 size_t ls_tile_scratch_stride(int nmax, int Nmax) {
@@ -603,12 +610,12 @@ size_t ls_tile_scratch_stride(int nmax, int Nmax) {
 
 // Frames into their size classes, and (adaptations >= 1) the zero counts of the tracks that the slot set-up of both
 // batched kernels looks up.  A.cls (zeroed header) / A.zflag (zeroed) / A.zloc / A.ztot are set by the caller.
-int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A) {
+int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A, long long track_t0) {
   hipLaunchKernelGGL(eaqhm_ls_classify_kernel, dim3((A.n_frames + 255) / 256), dim3(256), 0, ctx->stream, A);
   HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
-    hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(A.zchunks, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.L,
-                       A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
+    hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(A.zchunks, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.Lt,
+                       track_t0, A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
     HIP_TRY(ctx, hipGetLastError());
   }
   return EAQHM_OK;
@@ -621,7 +628,7 @@ int launch_ls_tile(eaqhm_ctx* ctx, LsArgs A, int grid) {
   const int ldx_max = 16 * TL_NTMAX + 16;
   const int TS = 32;
   const size_t lds_bytes = tl_lds_doubles(Kcmax, TS, ldx_max) * sizeof(double);
-  if (lds_bytes > 160 * 1024) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
+  if (lds_bytes > TL_LDS_LIMIT) return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (tile variant)");
   if (a0_lds_doubles(A0_M, 2, TZ_TB, TZ_NCH, 520, 64 * CI_NCH, Kcmax) * sizeof(double) > lds_bytes)
     return ctx->fail(EAQHM_EINVAL, "eaqhm_ls_batch: LDS budget exceeded (adaptation 0, tile variant)");
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)eaqhm_ls_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

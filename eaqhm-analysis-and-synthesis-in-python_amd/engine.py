@@ -12,8 +12,9 @@ Per adaptation a rank runs
 and the host reads back the error sums once to apply the stop rule of functions.py:394-396 — every rank
 computes the same SRER from the same reduced sums, so no broadcast of the decision is needed.
 
-Dense state lives in HBM for the whole run: am_current / fm_current as [Kmax][L] (time contiguous),
-frame-centre records as [No_ti][3*Kmax+1].  All numerics are in libeaqhm_hip.so; this module only
+State in HBM: the frame-centre records [No_ti][3*Kmax+1] for the whole run; am_current / fm_current as
+[Kmax][samples] (time contiguous) for the rank's own time range plus halo — or, for long files, one time block at a
+time, regenerated from the records (DeviceAnalysis).  All numerics are in libeaqhm_hip.so; this module only
 allocates buffers (torch-ROCm tensors), fills the small per-frame tables and sequences the launches.
 """
 import numpy as np
@@ -68,19 +69,20 @@ def ls_cost(N, Kc):
 
 
 class Sharding:
-    """Contiguous ranges of analysis instants per rank, balanced by the LS cost of their frames (SURVEY.md §8e:
-    "balanced by sum F(N,Kc), not by count": the cost of a frame varies ~2.5x with the pitch); `group` is a
-    torch.distributed process group or None for a single process.  Every rank derives the same bounds from the
-    same frame plan, so no communication is needed to agree on them."""
+    """One rank's view of a run sharded over `world` processes (`group` = a torch.distributed process group, or None
+    for a single process) and the collectives the adaptation loop needs.  Stateless about the ranges: `balance`
+    computes the instant ranges of a frame plan — every rank derives the same bounds from the same plan, so no
+    communication is needed to agree on them — and the engine that asked keeps them and hands them back to the
+    collectives (one Sharding may serve several engines, engine.run_interleaved)."""
 
     def __init__(self, rank=0, world=1, group=None):
         self.rank, self.world, self.group = int(rank), int(world), group
         self.collective = group is not None      # a 1-rank group still goes through the collectives (rehearsal)
-        self.bounds = None
 
     def balance(self, n_instants, cost=None):
-        """Fix the instant ranges: bounds[r] .. bounds[r+1] is rank r's.  `cost` = per-instant LS cost (zero for the
-        instants that are not analysed); None or all-zero -> equal counts."""
+        """Contiguous instant ranges, bounds[r] .. bounds[r+1] for rank r, balanced by the LS cost of their frames
+        ("balanced by sum F(N,Kc), not by count": the cost of a frame varies ~2.5x with the pitch).
+        `cost` = per-instant LS cost (zero for the instants that are not analysed); None or all-zero -> equal counts."""
         T, W = int(n_instants), self.world
         if cost is None or W == 1 or float(np.sum(cost)) <= 0.0:
             c = -(-T // W)
@@ -92,32 +94,36 @@ class Sharding:
             for r in range(1, W + 1):
                 b[r] = max(b[r], b[r - 1])
         b[W] = T
-        self.bounds = b
         return b
 
     def instants(self, n_instants, rank=None):
-        if self.bounds is None or self.bounds[-1] != n_instants:
-            self.balance(n_instants)
+        """Equal-count range of `rank` (what balance gives without costs)."""
+        b = self.balance(n_instants)
         r = self.rank if rank is None else rank
-        return self.bounds[r], self.bounds[r + 1]
+        return b[r], b[r + 1]
+
+    def _check(self, bounds, n_rows):
+        if bounds is None or len(bounds) != self.world + 1 or bounds[0] != 0 or bounds[-1] != n_rows:
+            raise ValueError("instant ranges %r do not belong to a buffer of %d rows on %d ranks" % (bounds, n_rows, self.world))
 
     def _all_gather_into(self, out, part):
         """out = concatenation over ranks of `part` (RCCL all-gather of equal parts)."""
         import torch.distributed as dist
         dist.all_gather_into_tensor(out, part, group=self.group)
 
-    def all_gather_rows(self, buf, n_instants):
+    def all_gather_rows(self, buf, bounds):
         """Every rank ends up with every rank's rows of `buf` (rank r owns rows bounds[r] .. bounds[r+1]).  The ranges
         differ in length, so this is a sum over ranks of the buffer with the foreign rows zeroed — done once per run,
         when the results are collected, or per adaptation only for inputs too short for the boundary exchange."""
         if not self.collective:
             return
-        lo, hi = self.instants(n_instants)
+        self._check(bounds, buf.shape[0])
+        lo, hi = bounds[self.rank], bounds[self.rank + 1]
         buf[:lo].zero_()
         buf[hi:].zero_()
         self.all_reduce_sum(buf)
 
-    def share_rows(self, buf, n_instants, margin):
+    def share_rows(self, buf, bounds, margin):
         """What the interpolation of one rank's time range reads from the other ranks' rows of `buf`: the `margin`
         rows on either side of its own range and the first rows of the file (pad knots of short runs).  Every rank
         contributes the first and the last `margin` rows of its range to one small all-gather and copies its two
@@ -126,10 +132,10 @@ class Sharding:
         Returns True if only boundary rows were exchanged."""
         if not self.collective:
             return False
-        self.instants(n_instants)
-        b = self.bounds
+        self._check(bounds, buf.shape[0])
+        b = bounds
         if margin < 4 or min(b[r + 1] - b[r] for r in range(self.world)) < margin:
-            self.all_gather_rows(buf, n_instants)
+            self.all_gather_rows(buf, bounds)
             return False
         import torch
         r, m = self.rank, margin
@@ -153,10 +159,44 @@ class Sharding:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
-class DeviceAnalysis:
-    """Buffers + launch sequence of one analysis run on one GPU (rank)."""
+class StalledPipeline(RuntimeError):
+    """A diagonal-tile pipeline of the LS kernels timed out waiting for its partner wave (eaqhm_ls_chol.h, spin_until):
+    a defect of the library, never a property of the input — reported apart from singular systems."""
 
-    def __init__(self, s, target, plan, f0min, max_adpt, device_index=0, shard=None, keep_raw=False, ctx=None):
+
+def srer_from_limbs(limbs, n, std_det):
+    """SRER in dB (functions.py:388: 20 log10(std(target) / std(target - s_recon)), population std) from the
+    fixed-point error sums of eaqhm_eval_synth (include/eaqhm_hip.h): three base-2^32 limbs of sum(d * 2^60), three of
+    sum(d^2 * 2^64), the count of non-finite (or absurdly large) samples.  Integer sums: the same value whatever
+    the number of ranks, blocks or time blocks that contributed.  NumPy semantics for the degenerate cases like the
+    reference's: a non-finite reconstruction gives nan, a perfect one +inf, a silent target -inf or nan."""
+    v = [int(x) for x in limbs]
+    if v[6]:
+        return np.float64(np.nan)
+    tot = (v[0] + (v[1] << 32) + (v[2] << 64)) / (1 << 60)          # int / int: correctly rounded
+    tot2 = (v[3] + (v[4] << 32) + (v[5] << 64)) / (1 << 64)
+    with np.errstate(all="ignore"):
+        mean = np.float64(tot) / np.float64(n)
+        var = np.float64(tot2) / np.float64(n) - mean * mean
+        return np.float64(20.0) * np.log10(np.float64(std_det) / np.sqrt(var))
+
+
+class DeviceAnalysis:
+    """Buffers + launch sequence of one analysis run on one GPU (rank).
+
+    Dense tracks.  Only two of the reference's seven (L, Kmax) arrays are ever read again (am_current / fm_current,
+    functions.py:159-160), and only inside the analysis windows of the frames.  A rank keeps them for ITS time range
+    plus a halo of max(wl) samples, [Kmax][t_hi - t_lo].  With `track_budget_bytes` set (long files)
+    they are not kept at all: the frame-centre records are the state that survives an adaptation (1/15 of the
+    samples), and the frames are worked off in TIME BLOCKS — per block the tracks of the block's samples (+- max(wl))
+    are regenerated from the previous adaptation's records into a block-sized buffer (eaqhm_eval_synth without
+    synthesis outputs), then the block's LS frames run.  The interpolation is a pure function of the records, so the
+    blocks see bit for bit the tracks the resident run sees (tests/test_gpu_fullsize.py)."""
+
+    TRACK_BYTES_PER_CELL = 8 + 8 + 2      # am, fm, and the library's zero counts (u16) per (slot, sample)
+
+    def __init__(self, s, target, plan, f0min, max_adpt, device_index=0, shard=None, keep_raw=False, ctx=None,
+                 track_budget_bytes=None):
         import torch
         self.torch = torch
         self.ctx = ctx if ctx is not None else Context(device_index)
@@ -176,8 +216,8 @@ class DeviceAnalysis:
         sh = self.shard
         cost = np.zeros(T)
         cost[p.frame_inst] = ls_cost(2 * p.frame_wl.astype(np.int64) + 1, 2 * p.frame_K.astype(np.int64) + 1)
-        sh.balance(T, cost)
-        self.i_lo, self.i_hi = sh.instants(T)
+        self.bounds = sh.balance(T, cost)
+        self.i_lo, self.i_hi = self.bounds[sh.rank], self.bounds[sh.rank + 1]
         mine = np.flatnonzero((p.frame_inst >= self.i_lo) & (p.frame_inst < self.i_hi))
         lo, hi = (int(mine[0]), int(mine[-1]) + 1) if len(mine) else (0, 0)
         self.f_lo, self.f_hi, self.nf = lo, hi, hi - lo
@@ -185,42 +225,58 @@ class DeviceAnalysis:
         def bound(r):
             if r <= 0:
                 return 0
-            if r >= sh.world or sh.bounds[r] >= T:
+            if r >= sh.world or self.bounds[r] >= T:
                 return L
-            return sh.bounds[r] * p.step
+            return self.bounds[r] * p.step
         self.s_lo, self.s_hi = bound(sh.rank), bound(sh.rank + 1)
-        self.t_lo = max(0, self.s_lo - p.wl_max)
-        self.t_hi = min(L, self.s_hi + p.wl_max)
+        # samples whose tracks this rank's frames look at: every window [c - wl, c + wl] and the sample before it
+        # (the zero counts of the LS kernels are differences of running counts)
+        self.halo = p.wl_max + 1
+        self.t_lo = max(0, self.s_lo - self.halo)
+        self.t_hi = min(L, self.s_hi + self.halo)
         # rows of the other ranks' records the interpolation of [t_lo, t_hi) reads: the halo, the spline range beyond it
         # (+-2, +4), run detection (+-41)
-        self.margin = -(-p.wl_max // p.step) + 48
+        self.margin = -(-self.halo // p.step) + 48
         self.partial_rows = False
         # instants whose run codes / spline moments the evaluation of [t_lo, t_hi) looks at
         self.sp_lo = max(0, (max(self.t_lo, 1) - 1) // p.step - 2)
         self.sp_hi = max(self.sp_lo + 1, min(T, (max(self.t_hi, 1) - 1) // p.step + 4))
 
-        def dev_i32(a):
-            return torch.as_tensor(np.ascontiguousarray(a[lo:hi]), dtype=i32, device=dev)
-
-        self.frame_inst, self.frame_c, self.frame_wl = dev_i32(p.frame_inst), dev_i32(p.frame_c), dev_i32(p.frame_wl)
-        self.frame_K = dev_i32(p.frame_K)
-        self.frame_f0 = torch.as_tensor(np.ascontiguousarray(p.frame_f0[lo:hi]), dtype=f64, device=dev)
-        # frame_prep also visits the frames just before this rank's first one whose empty-row seeding
-        # (functions.py:204-210) would be visible inside this rank's windows
+        # frame tables: this rank's frames, preceded by the frames just before its first one whose empty-row seeding
+        # (functions.py:204-210) would be visible inside its windows (frame_prep visits those too)
         ext = lo
         if self.nf:
             ext = int(np.searchsorted(p.frame_c, p.frame_c[lo] - p.wl_max, side="left"))
-        self.n_ext, self.e0 = hi - ext, lo - ext
-        self.frame_c_ext = torch.as_tensor(np.ascontiguousarray(p.frame_c[ext:hi]), dtype=i32, device=dev)
-        self.ncol_ext = torch.zeros(max(self.n_ext, 1), dtype=i32, device=dev)
-        self.cols_ext = torch.zeros(max(self.n_ext, 1) * K, dtype=i32, device=dev)
-        self.ncol = self.ncol_ext[self.e0:]
-        self.cols = self.cols_ext[self.e0 * K:]
+        self.ext0 = ext
+
+        def dev_i32(a):
+            return torch.as_tensor(np.ascontiguousarray(a[ext:hi]), dtype=i32, device=dev)
+
+        self._inst_x, self._c_x, self._wl_x, self._K_x = (dev_i32(p.frame_inst), dev_i32(p.frame_c), dev_i32(p.frame_wl),
+                                                           dev_i32(p.frame_K))
+        self._f0_x = torch.as_tensor(np.ascontiguousarray(p.frame_f0[ext:hi]), dtype=f64, device=dev)
+        n_x = max(hi - ext, 1)
+        self.ncol_ext = torch.zeros(n_x, dtype=i32, device=dev)
+        self.cols_ext = torch.zeros(n_x * K, dtype=i32, device=dev)
+        e0 = lo - ext
+        self.frame_inst, self.frame_c, self.frame_wl = self._inst_x[e0:], self._c_x[e0:], self._wl_x[e0:]
+        self.frame_K, self.frame_f0 = self._K_x[e0:], self._f0_x[e0:]
+        self.ncol = self.ncol_ext[e0:]
+        self.cols = self.cols_ext[e0 * K:]
         self.seeded = torch.zeros(L, dtype=torch.uint8, device=dev)
         self.any_seed = torch.zeros(1, dtype=i32, device=dev)
-        # dense tracks (functions.py:159-160) — harmonic-major
-        self.am_cur = torch.zeros(K, L, dtype=f64, device=dev)
-        self.fm_cur = torch.zeros(K, L, dtype=f64, device=dev)
+
+        # time blocks and the dense tracks (functions.py:159-160) — harmonic-major, [Kmax][samples of the window]
+        self.blocks = self._plan_blocks(track_budget_bytes)
+        self.streaming = track_budget_bytes is not None
+        if self.streaming:
+            self.seeded_all = torch.zeros(L, dtype=torch.uint8, device=dev)
+            self.any_seed_all = torch.zeros(1, dtype=i32, device=dev)
+        width = max([b[3] - b[2] for b in self.blocks] + [1])
+        self.track_cells = K * width
+        self._trk_am = torch.zeros(K * width, dtype=f64, device=dev)
+        self._trk_fm = torch.zeros(K * width, dtype=f64, device=dev)
+        self.track_t0, self.track_len = (self.blocks[0][2], self.blocks[0][3] - self.blocks[0][2]) if self.blocks else (0, 1)
         # frame-centre records, double-buffered: [0] = adaptation in flight, [1] = last accepted
         self.records = [torch.zeros(T, self.RS, dtype=f64, device=dev) for _ in range(2)]
         self.ph_knot = [torch.zeros(T, K, dtype=f64, device=dev) for _ in range(2)]
@@ -228,7 +284,8 @@ class DeviceAnalysis:
         self.code = torch.zeros(T, K, dtype=torch.uint8, device=dev)
         self.mom = torch.zeros(T, K + 1, dtype=f64, device=dev)
         self.partials = torch.zeros(self.ctx.eval_partials_len(0, L, p.step), dtype=f64, device=dev)
-        self.sums = torch.zeros(8, dtype=f64, device=dev)    # {sum d, sum d^2, n, SRER dB, LS faults, -, -, -}
+        # {sum d, sum d^2, n, SRER dB, LS breakdowns, stalled pipelines, -, -} + 8 int64 limbs (include/eaqhm_hip.h)
+        self.sums = torch.zeros(16, dtype=f64, device=dev)
         self.raw = None
         if keep_raw:
             self.raw = (torch.zeros(max(self.nf, 1), 2 * (2 * K + 1), dtype=f64, device=dev),
@@ -239,6 +296,51 @@ class DeviceAnalysis:
         self.seeded_on_break = None
         self.timeline = []          # (adaptation, stage, start_event, end_event) when profiling is on
         self.profile = False
+
+    # ------------------------------------------------------------------ tracks and time blocks
+    def _plan_blocks(self, budget):
+        """[(first frame, end frame, first sample, end sample)] in this rank's frame numbering: runs of consecutive frames
+        whose windows (+ the sample before) fit a track buffer of `budget` bytes; one block = the rank's whole range when
+        there is no budget."""
+        p = self.plan
+        if self.nf == 0:
+            return []
+        if budget is None:
+            return [(0, self.nf, self.t_lo, self.t_hi)]
+        c = p.frame_c[self.f_lo:self.f_hi].astype(np.int64)
+        width = int(budget) // (self.TRACK_BYTES_PER_CELL * p.Kmax)
+        need = 2 * self.halo + 1
+        if width < need:
+            raise ValueError("track_budget_bytes=%d holds %d samples of %d slots; one analysis window needs %d"
+                             % (budget, width, p.Kmax, need))
+        out, fa = [], 0
+        while fa < self.nf:
+            w_lo = max(0, int(c[fa]) - self.halo)
+            fb = int(np.searchsorted(c, w_lo + width - self.halo, side="left"))     # c + halo <= w_lo + width
+            fb = max(fb, fa + 1)
+            out.append((fa, min(fb, self.nf), w_lo, min(p.L, int(c[min(fb, self.nf) - 1]) + self.halo)))
+            fa = min(fb, self.nf)
+        return out
+
+    def _tracks(self, blk):
+        """(am, fm) views [Kmax][width] of the track buffer for a block's window, and the window."""
+        K = self.plan.Kmax
+        w = blk[3] - blk[2]
+        return self._trk_am[:K * w].view(K, w), self._trk_fm[:K * w].view(K, w), blk[2], w
+
+    @property
+    def am_cur(self):
+        """am_current of the resident window (functions.py:383) as [Kmax][samples]; absolute sample t is column
+        t - track_t0.  (Streaming runs hold only the block worked on last.)"""
+        return self._trk_am[:self.plan.Kmax * self.track_len].view(self.plan.Kmax, self.track_len)
+
+    @property
+    def fm_cur(self):
+        return self._trk_fm[:self.plan.Kmax * self.track_len].view(self.plan.Kmax, self.track_len)
+
+    def track_bytes(self):
+        """Bytes of dense-track state this engine holds (both arrays); the library adds 2 bytes per cell of zero counts."""
+        return 2 * 8 * self.track_cells
 
     # ------------------------------------------------------------------ stages
     def _mark(self):
@@ -256,18 +358,41 @@ class DeviceAnalysis:
         # allocation, and the rows of other ranks arrive with the all-gather.
         if self.nf == 0:
             return
-        if a > 0:
-            c.frame_prep(self.fm_cur, p.L, p.Kmax, self.frame_c_ext, self.n_ext, self.ncol_ext, self.cols_ext,
-                         self.seeded, self.any_seed)
-            if self.profile:
-                self.ncol_hist.append(self.ncol.clone())
         raw_a, raw_s = self.raw if self.raw is not None else (None, None)
+        K = p.Kmax
+        if self.streaming and a > 0:
+            self.seeded_all.zero_()
+            self.any_seed_all.zero_()
         e0 = self._mark()
-        c.ls_batch(0 if a == 0 else 1, self.s, p.L, p.fs, self.am_cur, self.fm_cur, p.Kmax, self.frame_inst,
-                   self.frame_c, self.frame_wl, self.frame_f0, self.frame_K, self.ncol, self.cols, self.seeded,
-                   self.any_seed, self.nf, p.wl_max, a, p.f0_stale, self.f0min, self.records[0], raw_a, raw_s)
+        for blk in (self.blocks if a > 0 else [(0, self.nf, 0, p.L)]):
+            fa, fb = blk[0], blk[1]
+            am = fm = None
+            t0, w = 0, p.L
+            if a > 0:
+                am, fm, t0, w = self._tracks(blk)
+                self.track_t0, self.track_len = t0, w
+                if self.streaming:
+                    # the block's tracks from the records of the last accepted adaptation (the interpolation and phase
+                    # integration of functions.py:346-375 again, for these samples only; code / mom are still its)
+                    c.eval_synth(self.records[1], self.code, self.mom, p.No_ti, K, p.step, p.fs, p.L, t0, t0 + w, 0, 0,
+                                 None, 0.0, am, fm, t0, w, None, None, None, None)
+                # frame_prep also visits the frames before the block whose seeded rows its windows can see
+                xa = int(np.searchsorted(p.frame_c, p.frame_c[self.f_lo + fa] - p.wl_max, side="left")) - self.ext0
+                xb = self.f_lo + fb - self.ext0
+                c.frame_prep(fm, p.L, t0, w, K, self._c_x[xa:xb], xb - xa, self.ncol_ext[xa:xb],
+                             self.cols_ext[xa * K:xb * K], self.seeded, self.any_seed)
+                if self.streaming:
+                    self.seeded_all |= self.seeded
+                    self.any_seed_all |= self.any_seed
+            c.ls_batch(0 if a == 0 else 1, self.s, p.L, p.fs, am, fm, t0, w, K, self.frame_inst[fa:fb],
+                       self.frame_c[fa:fb], self.frame_wl[fa:fb], self.frame_f0[fa:fb], self.frame_K[fa:fb],
+                       self.ncol[fa:fb], self.cols[fa * K:fb * K], self.seeded, self.any_seed, fb - fa, p.wl_max, a,
+                       p.f0_stale, self.f0min, self.records[0],
+                       None if raw_a is None else raw_a[fa:fb], None if raw_s is None else raw_s[fa:fb])
         e1 = self._mark()
         if self.profile:
+            if a > 0:
+                self.ncol_hist.append(self.ncol.clone())
             self.timeline.append((a, "ls", e0, e1))
         self.n_ls_frames += self.nf
 
@@ -275,15 +400,21 @@ class DeviceAnalysis:
         """Enqueue interpolation + synthesis + error sums of adaptation `a` (no host read)."""
         p, c, sh = self.plan, self.ctx, self.shard
         g0 = self._mark()
-        self.partial_rows = sh.share_rows(self.records[0], p.No_ti, self.margin) or self.partial_rows
+        self.partial_rows = sh.share_rows(self.records[0], self.bounds, self.margin) or self.partial_rows
         e0 = self._mark()
         if self.profile and sh.collective:
             self.timeline.append((a, "gather", g0, e0))
         c.spline_solve(self.records[0], p.No_ti, p.Kmax, p.step, self.code, self.mom, self.sp_lo, self.sp_hi)
         if self.s_hi > self.s_lo:
-            c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
-                         self.t_lo, self.t_hi, self.s_lo, self.s_hi, self.target, self.std_det, self.am_cur,
-                         self.fm_cur, self.ph_knot[0], self.s_hat[0], self.partials, self.sums)
+            if self.streaming or not self.blocks:      # synthesis and error sums only: the tracks are made per block
+                c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
+                             self.s_lo, self.s_hi, self.s_lo, self.s_hi, self.target, self.std_det, None, None, 0, 0,
+                             self.ph_knot[0], self.s_hat[0], self.partials, self.sums)
+            else:
+                am, fm, t0, w = self._tracks(self.blocks[0])
+                c.eval_synth(self.records[0], self.code, self.mom, p.No_ti, p.Kmax, p.step, p.fs, p.L,
+                             self.t_lo, self.t_hi, self.s_lo, self.s_hi, self.target, self.std_det, am, fm, t0, w,
+                             self.ph_knot[0], self.s_hat[0], self.partials, self.sums)
         else:
             self.sums.zero_()
         e1 = self._mark()
@@ -291,28 +422,29 @@ class DeviceAnalysis:
             self.timeline.append((a, "post", e0, e1))
 
     def post_result(self):
-        """SRER of the adaptation enqueued last (host float): the one device->host read of an adaptation.  The same
-        read carries the count of singular LS systems of that adaptation; like the reference, whose inv() raises
-        there (functions.py:465, :530), the run aborts with numpy.linalg.LinAlgError."""
+        """SRER of the adaptation enqueued last (numpy.float64): the one device->host read of an adaptation.  One
+        formula for every world size and block count: the ranks' fixed-point error sums are added as integers
+        (srer_from_limbs).  The same read carries the count of LS systems whose factorisation broke down in that
+        adaptation; like the reference, whose inv() raises on a singular matrix (functions.py:465, :530), the run
+        aborts with numpy.linalg.LinAlgError."""
         p, sh = self.plan, self.shard
-        if not sh.collective:
-            srer, faults = (float(v) for v in self.sums[3:5].cpu())
-        else:
-            red = self.sums[[0, 1, 4]]
-            sh.all_reduce_sum(red)
-            tot, tot2, faults = (float(v) for v in red.cpu())
-            n = float(p.L)
-            mean = tot / n
-            srer = float(20.0 * np.log10(self.std_det / np.sqrt(tot2 / n - mean * mean)))
+        words = self.sums.view(self.torch.int64)[8:16].clone()
+        words[7] = 0
+        counts = self.sums[4:6].to(self.torch.int64)
+        red = self.torch.cat((words, counts))
+        sh.all_reduce_sum(red)
+        red = red.cpu().numpy()
+        faults, stalled = int(red[8]), int(red[9])
+        if stalled > 0:
+            raise StalledPipeline("%d diagonal-tile pipeline(s) of the LS kernels timed out in this adaptation "
+                                  "(library defect, not a singular system)" % stalled)
         if faults > 0:
-            raise np.linalg.LinAlgError("Singular matrix (%d frame(s) of this adaptation: a collapsed Cholesky pivot "
-                                        "in the normal equations)" % int(faults))
-        if not np.isfinite(srer):
-            raise FloatingPointError("SRER of the adaptation is not finite (%r)" % srer)
-        return srer
+            raise np.linalg.LinAlgError("Singular matrix (%d frame(s) of this adaptation: Cholesky breakdown "
+                                        "of the normal equations)" % faults)
+        return srer_from_limbs(red[:8], p.L, self.std_det)
 
     def post_stage(self, a):
-        """Interpolation + synthesis + SRER of adaptation `a`; returns the SRER (host float)."""
+        """Interpolation + synthesis + SRER of adaptation `a`; returns the SRER."""
         self.post_launch(a)
         return self.post_result()
 
@@ -341,13 +473,14 @@ class DeviceAnalysis:
             self.SRER.append(np.float64(srer))
             if on_adaptation is not None:
                 on_adaptation(a, self)
-            if a != 0 and self.SRER[a] <= self.SRER[a - 1]:                      # functions.py:394-396
+            # functions.py:394-396.  A nan SRER compares False (the loop goes on, as in the reference), inf <= inf breaks.
+            if a != 0 and self.SRER[a] <= self.SRER[a - 1]:
                 # Q8: the empty-row seeding of THIS adaptation wrote into the array the previous
                 # adaptation's result aliases (functions.py:210, :383, :400)
-                flag = self.any_seed.clone()
+                flag = (self.any_seed_all if self.streaming else self.any_seed).clone()
                 self.shard.all_reduce_sum(flag)
                 if int(flag.item()):
-                    seeded = self.seeded.to(self.torch.int32)
+                    seeded = (self.seeded_all if self.streaming else self.seeded).to(self.torch.int32)
                     self.shard.all_reduce_sum(seeded)
                     self.seeded_on_break = self.torch.nonzero(seeded).flatten().cpu().numpy()
                 break
@@ -369,7 +502,7 @@ class DeviceAnalysis:
         p, K, sh = self.plan, self.plan.Kmax, self.shard
         s_hat, ph = self.s_hat[1], self.ph_knot[1]
         if sh.collective and self.partial_rows:      # only boundary rows travelled during the loop
-            sh.all_gather_rows(self.records[1], p.No_ti)
+            sh.all_gather_rows(self.records[1], self.bounds)
         if sh.collective:
             s_hat = s_hat.clone()
             s_hat[:self.s_lo] = 0

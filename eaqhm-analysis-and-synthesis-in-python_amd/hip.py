@@ -24,15 +24,15 @@ SYMBOLS = (
     ("eaqhm_debug_read", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("eaqhm_device_info", C.c_int, [_P, C.POINTER(_I32)]),
     ("eaqhm_ls_faults", C.c_int, [_P, C.POINTER(_I32)]),
-    ("eaqhm_frame_prep", C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
-    ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    ("eaqhm_frame_prep", C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
+    ("eaqhm_ls_batch", C.c_int, [_P, _I32, _P, _I64, _F64, _P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _I32, _I32, _I32, _F64, _F64, _P, _P, _P]),
     ("eaqhm_ls_explicit", C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _P, _F64, _P, _P]),
     ("eaqhm_phase_integrate", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     ("eaqhm_spline_solve", C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     ("eaqhm_spline_solve_range", C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     ("eaqhm_eval_synth", C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F64, _I64, _I64, _I64, _I64, _I64, _P, _F64,
-                                    _P, _P, _P, _P, _P, _P]),
+                                    _P, _P, _I64, _I64, _P, _P, _P, _P]),
     ("eaqhm_eval_partials_len", _I64, [_I64, _I64, _I32]),
 )
 
@@ -130,23 +130,25 @@ class Context:
         return [int(v) for v in out]
 
     def ls_faults(self):
-        """LS systems with a collapsed Cholesky pivot since the last read (waits for the stream, clears the count)."""
-        n = _I32(0)
-        self._ck(self.lib.eaqhm_ls_faults(self.h, C.byref(n)))
-        return int(n.value)
+        """(LS systems whose Cholesky broke down, stalled diagonal pipelines) since the last read (waits for the stream,
+        clears the counts)."""
+        n = (_I32 * 2)()
+        self._ck(self.lib.eaqhm_ls_faults(self.h, n))
+        return int(n[0]), int(n[1])
 
     def sync(self):
         self._ck(self.lib.eaqhm_sync(self.h))
 
     # ---- thin wrappers (argument order = header order)
-    def frame_prep(self, fm_cur, L, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed):
-        self._ck(self.lib.eaqhm_frame_prep(self.h, _ptr(fm_cur), L, Kmax, _ptr(frame_c), n_frames, _ptr(ncol),
-                                           _ptr(cols), _ptr(seeded), _ptr(any_seed)))
+    def frame_prep(self, fm_cur, L, track_t0, track_len, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed):
+        self._ck(self.lib.eaqhm_frame_prep(self.h, _ptr(fm_cur), L, track_t0, track_len, Kmax, _ptr(frame_c), n_frames,
+                                           _ptr(ncol), _ptr(cols), _ptr(seeded), _ptr(any_seed)))
 
-    def ls_batch(self, mode, s, L, fs, am_cur, fm_cur, Kmax, frame_inst, frame_c, frame_wl, frame_f0, frame_K,
-                 ncol, cols, seeded, any_seed, n_frames, wl_max, a_iter, f0_stale, f0min, records,
+    def ls_batch(self, mode, s, L, fs, am_cur, fm_cur, track_t0, track_len, Kmax, frame_inst, frame_c, frame_wl,
+                 frame_f0, frame_K, ncol, cols, seeded, any_seed, n_frames, wl_max, a_iter, f0_stale, f0min, records,
                  raw_amp=None, raw_slope=None):
-        self._ck(self.lib.eaqhm_ls_batch(self.h, mode, _ptr(s), L, float(fs), _ptr(am_cur), _ptr(fm_cur), Kmax,
+        self._ck(self.lib.eaqhm_ls_batch(self.h, mode, _ptr(s), L, float(fs), _ptr(am_cur), _ptr(fm_cur), track_t0,
+                                         track_len, Kmax,
                                          _ptr(frame_inst), _ptr(frame_c), _ptr(frame_wl), _ptr(frame_f0),
                                          _ptr(frame_K), _ptr(ncol), _ptr(cols), _ptr(seeded), _ptr(any_seed),
                                          n_frames, wl_max, a_iter, float(f0_stale), float(f0min),
@@ -165,11 +167,11 @@ class Context:
                                                    _ptr(mom)))
 
     def eval_synth(self, records, code, mom, No_ti, Kmax, step, fs, L, t_lo, t_hi, s_lo, s_hi, target, std_det,
-                   am_out, fm_out, ph_knot, s_hat, partials, sums_out):
+                   am_out, fm_out, track_t0, track_len, ph_knot, s_hat, partials, sums_out):
         self._ck(self.lib.eaqhm_eval_synth(self.h, _ptr(records), _ptr(code), _ptr(mom), No_ti, Kmax,
                                            step, float(fs), L, t_lo, t_hi, s_lo, s_hi, _ptr(target), float(std_det),
-                                           _ptr(am_out), _ptr(fm_out), _ptr(ph_knot), _ptr(s_hat), _ptr(partials),
-                                           _ptr(sums_out)))
+                                           _ptr(am_out), _ptr(fm_out), track_t0, track_len, _ptr(ph_knot), _ptr(s_hat),
+                                           _ptr(partials), _ptr(sums_out)))
 
     def eval_partials_len(self, t_lo, t_hi, step):
         return int(self.lib.eaqhm_eval_partials_len(t_lo, t_hi, step))

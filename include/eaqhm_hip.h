@@ -18,8 +18,12 @@
  *
  * Layouts ("harmonic-major" = the reference's (L, Kmax) arrays transposed so time is contiguous)
  *  - s, target, s_hat       double[L]
- *  - am_cur, fm_cur         double[Kmax][L]         dense tracks of the previous adaptation
- *                                                   (functions.py:159-160, :337-338, :375, :383)
+ *  - am_cur, fm_cur         double[Kmax][track_len] dense tracks of the previous adaptation (functions.py:159-160,
+ *                                                   :337-338, :375, :383) for the samples [track_t0, track_t0 +
+ *                                                   track_len) of the file: the whole file (0, L), one rank's time
+ *                                                   range plus halo, or one time block of a long file (the reference
+ *                                                   keeps seven such (L, Kmax) arrays resident).  A frame window
+ *                                                   [c-wl-1, c+wl] handed to eaqhm_ls_batch must lie inside it.
  *  - records                double[No_ti][3*Kmax+1] one row per analysis instant: |a_k| (Kmax), f_k (Kmax),
  *                                                   arg a_k (Kmax) written at functions.py:316-324, then the
  *                                                   DC term a0 (functions.py:303).  Rows of one contiguous
@@ -60,12 +64,15 @@ int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value);
  * workgroup): {setup, basis build, contraction, factorisation total..., see csrc/eaqhm_ls_tile.hip STAMP} */
 int eaqhm_debug_read(eaqhm_ctx* ctx, uint64_t h_out[16]);
 /* singular systems: the reference aborts with numpy.linalg.LinAlgError from inv() when a frame's normal matrix is
- * singular (functions.py:465, :530).  The kernels factorise by Cholesky; a pivot that collapses to <= 1e-12 of its
- * diagonal entry (two identical basis columns, a slot whose track duplicates another) is counted, per frame, in a
- * device counter instead of being passed on as a finite but meaningless solution.  eaqhm_ls_faults waits for the
- * stream, returns the count since the last read and clears it; eaqhm_eval_synth also reports (and clears) it in
- * sums_out[4], so the adaptation loop needs no extra device->host read.  The host raises LinAlgError. */
-int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t* h_count);
+ * singular — an exactly zero LU pivot (functions.py:465, :530); an ill-conditioned system is solved and returned.  The
+ * kernels factorise by Cholesky; what corresponds to the exact zero is a BREAKDOWN of the factorisation: a pivot that
+ * is not positive or has fallen to <= 2.5e-13 (order x eps) of its original diagonal entry, as two identical basis
+ * columns give.  Such frames are counted in a device counter (h_count[0]); ill-conditioned but factorisable systems are
+ * solved like the reference solves them.  h_count[1] counts diagonal-tile pipelines whose internal hand-shake timed
+ * out — never nonzero unless the library has a bug; the host raises RuntimeError for it, LinAlgError for h_count[0].
+ * eaqhm_ls_faults waits for the stream, returns the counts since the last read and clears them; eaqhm_eval_synth also
+ * reports (and clears) them in sums_out[4..5], so the adaptation loop needs no extra device->host read. */
+int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t h_count[2]);
 /* library / device facts: fills {n_cu, lds_bytes, clock_khz, abi_version} */
 int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
 
@@ -77,8 +84,9 @@ int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
  *   ncol[f]            number of active slots of frame f
  *   cols[f*Kmax + j]   j-th active slot (ascending)
  *   any_seed           int32[1], nonzero if any frame was seeded                                     */
-int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int32_t Kmax, const int32_t* frame_c,
-                     int32_t n_frames, int32_t* ncol, int32_t* cols, uint8_t* seeded, int32_t* any_seed);
+int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int64_t track_t0, int64_t track_len, int32_t Kmax,
+                     const int32_t* frame_c, int32_t n_frames, int32_t* ncol, int32_t* cols, uint8_t* seeded,
+                     int32_t* any_seed);
 
 /* the per-frame least squares, batched over frames ---------------------------------------------------
  * Replaces, for every analysed frame of one adaptation:
@@ -101,7 +109,8 @@ int eaqhm_frame_prep(eaqhm_ctx* ctx, const double* fm_cur, int64_t L, int32_t Km
  *   column order [negative block | DC | positive block] (NULL to skip) — what the two seam functions
  *   return.                                                                                           */
 int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int64_t L, double fs, const double* am_cur,
-                   const double* fm_cur, int32_t Kmax, const int32_t* frame_inst, const int32_t* frame_c,
+                   const double* fm_cur, int64_t track_t0, int64_t track_len, int32_t Kmax,
+                   const int32_t* frame_inst, const int32_t* frame_c,
                    const int32_t* frame_wl, const double* frame_f0, const int32_t* frame_K, const int32_t* ncol,
                    const int32_t* cols, const uint8_t* seeded, const int32_t* any_seed, int32_t n_frames,
                    int32_t wl_max, int32_t a_iter, double f0_stale, double f0min, double* records, double* raw_amp,
@@ -142,18 +151,26 @@ int eaqhm_spline_solve_range(eaqhm_ctx* ctx, const double* records, int32_t No_t
  * unwrapped phase), :383 (am_current), :385 (additive synthesis) and :388 (SRER).
  * Samples [t_lo, t_hi) are produced (the whole signal when 0, L); the error sums cover [s_lo, s_hi)
  * inside that range (a rank of a time-sharded run produces its range plus a halo but sums only its own).
- *   am_out, fm_out   double[Kmax][L]   next adaptation's am_current / fm_current
+ *   am_out, fm_out   double[Kmax][track_len]: next adaptation's am_current / fm_current for the samples
+ *                    [track_t0, track_t0 + track_len) >= [t_lo, t_hi); both NULL: no track output (a long file's
+ *                    synthesis pass: its tracks are regenerated block by block from the records)
  *   ph_knot          double[No_ti][Kmax] dense phase at the instants (what functions.py:411 packs)
- *   s_hat            double[L]
- *   partials         double[2*n_blocks] scratch for the deterministic two-level reduction
- *   sums_out         double[8]: {sum d, sum d^2, n, SRER dB, LS faults since the last read (see eaqhm_ls_faults), -, -, -}
- *                    with d = target - s_hat over [s_lo,s_hi); SRER uses std_det (functions.py:161) and is only
- *                    meaningful for a full range.                                                    */
+ *   s_hat            double[L]; NULL: tracks only — no synthesis, no ph_knot, no error sums (target, ph_knot,
+ *                    partials, sums_out may then be NULL too)
+ *   partials         8-byte words, eaqhm_eval_partials_len of them: per-block error sums
+ *   sums_out         double[16]: {sum d, sum d^2, n, SRER dB, LS breakdowns and stalled pipelines since the last read
+ *                    (see eaqhm_ls_faults), -, -, then eight int64 bit patterns} with d = target - s_hat over
+ *                    [s_lo,s_hi).  The int64 words are the same sums in fixed point — three base-2^32 limbs of
+ *                    d*2^60, three of d^2*2^64, the number of samples with |d| >= 2^20 or non-finite, 0 — which add
+ *                    up exactly over blocks, ranks and time blocks, so the SRER (functions.py:388, the input of the
+ *                    stop rule :394) does not depend on how the file was split; sums_out[3] is that SRER for this
+ *                    call's range alone (std_det: functions.py:161).                                  */
 int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uint8_t* code, const double* mom,
                      int32_t No_ti, int32_t Kmax, int32_t step, double fs, int64_t L, int64_t t_lo, int64_t t_hi,
                      int64_t s_lo, int64_t s_hi, const double* target, double std_det, double* am_out,
-                     double* fm_out, double* ph_knot, double* s_hat, double* partials, double* sums_out);
-/* number of doubles `partials` must hold for a given range */
+                     double* fm_out, int64_t track_t0, int64_t track_len, double* ph_knot, double* s_hat,
+                     double* partials, double* sums_out);
+/* number of 8-byte words `partials` must hold for a given range */
 int64_t eaqhm_eval_partials_len(int64_t t_lo, int64_t t_hi, int32_t step);
 
 #ifdef __cplusplus

@@ -51,3 +51,20 @@ def unpack_records(g, a, with_fm=True):
         arr[mask] = g["rec%d_%s" % (a, name)]
         out[name] = arr
     return out
+
+
+def record_measurement(name, **values):
+    """Numbers a GPU test measured next to what the reference gave (not assertions: evidence).  Collected in
+    gpurun_out/parity_measurements.json on the GPU box; the round's copy is committed under profiles/."""
+    import json
+    path = os.path.join(ROOT, "gpurun_out", "parity_measurements.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        try:
+            data = json.load(open(path))
+        except ValueError:
+            data = {}
+    data[name] = values
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)

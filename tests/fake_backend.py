@@ -12,16 +12,16 @@ class OracleBackend:
     device = torch.device("cpu")
 
     def eval_partials_len(self, t_lo, t_hi, step):
-        return 2
+        return 8
 
-    # ---- functions.py:202-213
-    def frame_prep(self, fm_cur, L, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed):
+    # ---- functions.py:202-213   (fm_cur: [Kmax][track_len] window that starts at sample track_t0)
+    def frame_prep(self, fm_cur, L, track_t0, track_len, Kmax, frame_c, n_frames, ncol, cols, seeded, any_seed):
         fm = fm_cur.numpy()
         seeded.zero_()
         any_seed.zero_()
         for f in range(n_frames):
             c = int(frame_c[f])
-            nz = np.flatnonzero(fm[:, c])
+            nz = np.flatnonzero(fm[:, c - track_t0])
             if len(nz) == 0:
                 seeded[c] = 1
                 any_seed[0] = 1
@@ -30,14 +30,17 @@ class OracleBackend:
             cols[f * Kmax:f * Kmax + len(nz)] = torch.as_tensor(nz, dtype=torch.int32)
 
     # ---- functions.py:187-197 / :244-324
-    def ls_batch(self, mode, s, L, fs, am_cur, fm_cur, Kmax, frame_inst, frame_c, frame_wl, frame_f0, frame_K,
-                 ncol, cols, seeded, any_seed, n_frames, wl_max, a_iter, f0_stale, f0min, records,
+    def ls_batch(self, mode, s, L, fs, am_cur, fm_cur, track_t0, track_len, Kmax, frame_inst, frame_c, frame_wl,
+                 frame_f0, frame_K, ncol, cols, seeded, any_seed, n_frames, wl_max, a_iter, f0_stale, f0min, records,
                  raw_amp=None, raw_slope=None):
         sig = s.numpy()
         rec = records.numpy()
-        Fmax_unused = None
-        am = am_cur.numpy().T.copy() if mode == 1 else None      # (L, Kmax) like the reference
-        fm = fm_cur.numpy().T.copy() if mode == 1 else None
+        am = fm = None
+        if mode == 1:                                            # (L, Kmax) like the reference; NaN where not resident
+            am = np.full((L, Kmax), np.nan)
+            fm = np.full((L, Kmax), np.nan)
+            am[track_t0:track_t0 + track_len] = am_cur.numpy().T
+            fm[track_t0:track_t0 + track_len] = fm_cur.numpy().T
         seeds = np.flatnonzero(seeded.numpy()) if mode == 1 and int(any_seed[0]) else np.array([], dtype=int)
         sp = 0
         for f in range(n_frames):
@@ -81,24 +84,39 @@ class OracleBackend:
 
     # ---- functions.py:337-388
     def eval_synth(self, records, code, mom, No_ti, Kmax, step, fs, L, t_lo, t_hi, s_lo, s_hi, target, std_det,
-                   am_out, fm_out, ph_knot, s_hat, partials, sums_out):
+                   am_out, fm_out, track_t0, track_len, ph_knot, s_hat, partials, sums_out):
         rec = records.numpy()[:No_ti]
         ti = np.arange(1, L, step)
         c = ti - 1
-        am = np.zeros((L, Kmax))
-        fm = np.zeros((L, Kmax))
-        ph = np.zeros((L, Kmax))
-        am[c], fm[c], ph[c] = rec[:, :Kmax], rec[:, Kmax:2 * Kmax], rec[:, 2 * Kmax:3 * Kmax]
-        a0, fm_next = O.interpolate_tracks(rec[:, 3 * Kmax].copy(), am, fm, ph, ti, step, fs, L)
+        key = hash(rec.tobytes())        # (a streaming run asks for the same records once per time block)
+        if getattr(self, "_interp_key", None) != key:
+            am = np.zeros((L, Kmax))
+            fm = np.zeros((L, Kmax))
+            ph = np.zeros((L, Kmax))
+            am[c], fm[c], ph[c] = rec[:, :Kmax], rec[:, Kmax:2 * Kmax], rec[:, 2 * Kmax:3 * Kmax]
+            a0, fm_next = O.interpolate_tracks(rec[:, 3 * Kmax].copy(), am, fm, ph, ti, step, fs, L)
+            self._interp_key, self._interp = key, (am, ph, a0, fm_next)
+        am, ph, a0, fm_next = self._interp
         sh = a0 + 2 * (am * np.cos(ph)).sum(axis=1)
-        am_out.numpy()[:, t_lo:t_hi] = am[t_lo:t_hi].T
-        fm_out.numpy()[:, t_lo:t_hi] = fm_next[t_lo:t_hi].T
+        if am_out is not None:
+            am_out.numpy()[:, t_lo - track_t0:t_hi - track_t0] = am[t_lo:t_hi].T
+            fm_out.numpy()[:, t_lo - track_t0:t_hi - track_t0] = fm_next[t_lo:t_hi].T
+        if s_hat is None:
+            return
         s_hat.numpy()[t_lo:t_hi] = sh[t_lo:t_hi]
         inside = (c >= t_lo) & (c < t_hi)
         ph_knot.numpy()[inside] = ph[c[inside]]
         d = target.numpy()[s_lo:s_hi] - sh[s_lo:s_hi]
         n = float(s_hi - s_lo)
         so = sums_out.numpy()
+        so[:] = 0
         so[0], so[1], so[2] = d.sum(), (d * d).sum(), n
+        # the fixed-point error sums of include/eaqhm_hip.h: sum of trunc(d * 2^60) and of trunc(d^2 * 2^64) as exact
+        # integers, cut into base-2^32 limbs (any cut that adds up to the same integer serves the host's recombination)
+        tot = sum(int(v) for v in np.trunc(d * 2.0 ** 60).astype(object))
+        tot2 = sum(int(v) for v in np.trunc((d * d) * 2.0 ** 64).astype(object))
+        limbs = so.view(np.int64)[8:16]
+        for j, v in ((0, tot), (3, tot2)):
+            limbs[j], limbs[j + 1], limbs[j + 2] = v & 0xffffffff, (v >> 32) & 0xffffffff, v >> 64
         mean = so[0] / n
         so[3] = 20 * np.log10(std_det / np.sqrt(so[1] / n - mean * mean))

@@ -24,6 +24,8 @@ Usage:
                                                        # provokes the empty-row seeding branch (functions.py:204-242)
     python tests/golden/make_golden.py synth48k_p80    # 0.6 s synthetic @48 kHz, partials=80, maxAdpt=2
     python tests/golden/make_golden.py prep48k60       # pre-processing of the 60 s @48 kHz bench workload
+    python tests/golden/make_golden.py synth16k_60s    # the headline workload at full size: 60 s @16 kHz, maxAdpt=5 (~1 h, ~5 GB)
+    python tests/golden/make_golden.py synth48k_2s     # 2 s synthetic @48 kHz full band, maxAdpt=1 (~10 min)
 """
 import os
 import sys
@@ -379,6 +381,44 @@ def job_synth48k_p80():
     save("synth48k_0p6s_p80_adpt2.npz", o)
 
 
+def _slim_full_size(o, decim):
+    """Full-size runs: keep SRER, the per-adaptation checksums, the frame geometry and a decimated s_recon."""
+    for k in ("det_cells", "det_am", "det_fm", "det_pk", "swipe_track"):
+        o.pop(k, None)
+    sr = o.pop("s_recon")
+    o["s_recon_decim"] = np.int64(decim)
+    o["s_recon_every"] = np.array(sr[::decim])
+    o["s_recon_sums"] = np.array([sr.sum(), np.abs(sr).sum(), (sr * sr).sum(), float(len(sr))])
+    o["f0s_5ms"] = np.ascontiguousarray(o["f0s_5ms"][:, :2])
+
+
+def job_synth16k_60s():
+    """BASELINE.json configs[3], the workload the metric is quoted on, through the reference at its own size:
+    60 s @16 kHz, `female`, maxAdpt=5 (63,936 LS frames per adaptation)."""
+    fs = 16000
+    x = synth_speech_int16(60.0, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(dense_adpts=(), rec_adpts=())
+    o = run_reference(wav, "female", cap, maxAdpt=5)
+    os.unlink(wav)
+    _slim_full_size(o, 8)
+    save("synth16k_60s_adpt5.npz", o)
+
+
+def job_synth48k_2s():
+    """Full-band 48 kHz (near-Nyquist partials) at a size between the 0.6 s fixture and the 60 s bench
+    workload: 2 s, maxAdpt=1; the pitch comes from the reference's own SWIPE' on these 2 s."""
+    fs = 48000
+    x = synth_speech_int16(2.0, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(dense_adpts=(), rec_adpts=())
+    o = run_reference(wav, "female", cap, maxAdpt=1)
+    o["wav_int16"] = x
+    os.unlink(wav)
+    _slim_full_size(o, 4)
+    save("synth48k_2s_adpt1.npz", o)
+
+
 def job_prep48k60():
     xs = synth_speech_int16(60.0, 48000)
     r = prep_only(xs, 48000, "female")
@@ -467,6 +507,6 @@ def job_units():
 if __name__ == "__main__":
     jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
                 prep=job_prep, units=job_units, seed16k=job_seed16k, synth48k_p80=job_synth48k_p80,
-                prep48k60=job_prep48k60)
+                prep48k60=job_prep48k60, synth16k_60s=job_synth16k_60s, synth48k_2s=job_synth48k_2s)
     for j in sys.argv[1:]:
         jobs[j]()

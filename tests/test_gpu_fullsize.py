@@ -39,50 +39,124 @@ def test_config3_sa19_x10_reference_anchor():
     assert abs(20 * np.log10(np.std(s) / np.std(d)) - max(eng.SRER)) < 1e-9     # returned signal = best adaptation
 
 
-def test_config4_synthetic_60s_properties():
-    """Synthetic 60 s @16 kHz (960,000 samples, 63,936 LS frames per adaptation)."""
+def test_config4_synthetic_60s_against_the_reference():
+    """BASELINE config 4, the workload the frames/s metric is quoted on (synthetic 60 s @16 kHz, `female`, maxAdpt=5:
+    960,000 samples, 63,936 LS frames per adaptation), against the REFERENCE ITSELF run at this size
+    (tests/golden/make_golden.py synth16k_60s, 42 min of CPU): the SRER of all five executed adaptations to 1e-6 dB
+    (north-star bar: final SRER within 0.1 dB), the checksums of the frame-centre records and of the dense state after
+    every adaptation (incl. the rejected one), every 8th sample of s_recon, the frame geometry and the struct flags."""
+    from conftest import record_measurement
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.functions import pack_results
     from eaqhm_amd.synth import synth_speech_int16
+    g = load_golden("synth16k_60s_adpt5.npz")
     fs = 16000
     s = synth_speech_int16(60.0, fs) / 32768.0
-    track = load_golden("prep_fixtures.npz")["synth16k_60s_f0s_5ms"]
-    plan, eng, fin = _run(s, fs, track, 3)
-    assert plan.n_frames == 63936 and plan.L == 960000
+    assert np.array_equal(g["f0s_5ms"], load_golden("prep_fixtures.npz")["synth16k_60s_f0s_5ms"])   # bench.py's pitch grid
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    assert np.array_equal([float(f.isVoiced) for f in frames], g["vuv_isVoiced"])
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, g["f0s_5ms"], frames, fstep, 15, 3, 32, 0)
+    assert plan.n_frames == 63936 and plan.L == 960000 and plan.No_ti == 64000
+    sh = g["ls_shapes_iqhm"]
+    assert np.array_equal(2 * plan.frame_wl + 1, sh[:, 0]) and np.array_equal(2 * plan.frame_K + 1, sh[:, 1])
+    assert np.array_equal(plan.ti[plan.analysed], g["ti_a0"]) and np.abs(plan.frame_f0 - g["f0_a0"]).max() == 0
+    assert plan.f0_stale == g["stale_f0"][0, 1]
+    eng = DeviceAnalysis(s, s, plan, 160, 5)
+    eng.profile = True                                  # keeps the active-slot counts of every adaptation
+    seen = {}
+
+    def hook(a, e):
+        rec = e.records[0][:plan.No_ti]
+        K = plan.Kmax
+        am, fm = e.am_cur, e.fm_cur
+        seen[a] = [float(v) for v in (
+            (rec[:, :K] != 0).sum(), rec[:, :K].sum(), rec[:, K:2 * K].sum(), rec[:, 3 * K].sum(), am.sum(), fm.sum(),
+            e.s_hat[0].sum(), (am != 0).sum(), (fm != 0).sum())]
+
+    eng.run(on_adaptation=hook)
     srer = np.array(eng.SRER)
-    assert srer[0] > 40 and np.all(np.isfinite(srer))
-    k = len(srer)
-    assert np.all(np.diff(srer[:k - 1]) > 0) if k > 2 else True                 # improved until the stop (or the cap)
-    best = srer.max()
+    record_measurement("synth16k_60s", srer_hip=[float(v) for v in srer], srer_reference=[float(v) for v in g["SRER"]])
+    assert len(srer) == len(g["SRER"]) == 5
+    assert np.abs(srer - g["SRER"]).max() < 1e-6
+    for a in range(5):
+        rs, ds, got = g["recsum%d" % a], g["densesum%d" % a], seen[a]
+        assert abs(got[0] - int(rs[0])) <= 40                                  # accepted cells (of ~2 M)
+        assert abs(got[1] - rs[1]) <= 1e-7 * abs(rs[1]) and abs(got[2] - rs[2]) <= 1e-7 * abs(rs[2])
+        assert abs(got[3] - rs[4]) <= 1e-6
+        assert abs(got[4] - ds[0]) <= 1e-7 * abs(ds[0])                        # dense am_recon
+        assert abs(got[5] - ds[3]) <= 1e-6 * abs(ds[3])                        # fm_current
+        assert abs(got[6] - ds[5]) <= 1e-7 * max(abs(ds[5]), 1.0)              # s_recon_tmp
+        assert abs(got[7] - int(ds[6])) <= 600 and abs(got[8] - int(ds[7])) <= 600
+    if len(eng.ncol_hist):                                                     # adaptation 1: same active slots per frame
+        assert np.array_equal(2 * eng.ncol_hist[0].cpu().numpy() + 1, g["ls_shapes_eaqhm"][:63936, 1])
+    fin = eng.final_arrays()
+    dec = int(g["s_recon_decim"])
+    assert np.abs(fin["s_recon"][::dec] - g["s_recon_every"]).max() <= 1e-9
+    sums = g["s_recon_sums"]
+    assert abs(fin["s_recon"].sum() - sums[0]) <= 1e-6 and abs((fin["s_recon"] ** 2).sum() - sums[2]) <= 1e-7 * sums[2]
     d = s - fin["s_recon"]
-    assert abs(20 * np.log10(np.std(s) / np.std(d)) - best) < 1e-9              # host-recomputed SRER of s_recon
-    # every analysed instant has harmonics, frequencies are harmonic-ordered, amplitudes positive
-    an = plan.analysed
-    assert np.all((fin["am"][an] > 0).sum(axis=1) > 0) and np.all(fin["am"] >= 0)
+    assert abs(20 * np.log10(np.std(s) / np.std(d)) - srer.max()) < 1e-9       # host-recomputed SRER of s_recon
+    det = pack_results(plan, fin)
+    assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
+    assert np.array_equal([d.isSpeech for d in det], g["det_isSpeech"])
+    v = g["det_isVoiced"]
+    assert np.abs(np.array([float(d.a0) for d in det if d.isVoiced]) - g["det_a0"][v]).max() <= 1e-8
+    lens = np.array([len(d.amplitudes) if d.isVoiced else 0 for d in det])
+    assert np.mean(lens == g["det_len"]) >= 0.999
     # bit reproducibility (the frame queue changes which workgroup gets which frame, never the arithmetic)
-    plan2, eng2, fin2 = _run(s, fs, track, 3)
-    assert np.array_equal(np.array(eng2.SRER), srer)
-    assert np.array_equal(fin2["s_recon"], fin["s_recon"]) and np.array_equal(fin2["am"], fin["am"])
+    eng2 = DeviceAnalysis(s, s, plan, 160, 1)
+    eng2.run()
+    assert np.array_equal(np.array(eng2.SRER), srer[:2])
 
 
-def test_config5_60s_48khz_memory_bound():
-    """SURVEY §8f row 4 (long files): the reference keeps seven dense L x Kmax float64 arrays (60 s @48 kHz: 7 x 3.7 GB);
-    this path keeps two plus the frame-centre records.  Instead of streaming the tracks in time blocks the whole file
-    stays resident — this test pins the bound that makes that acceptable: one adaptation of BASELINE config 5
-    (2,880,000 samples, 191,936 large frames, Kmax 159) peaks below 12 GB of the 288 GB of HBM (buffers of the engine;
-    the library's own grow-only scratch — per-workgroup factor tiles and the zero counts, about 2.5 GB here — comes on top)."""
+def test_config5_60s_48khz_time_block_streaming():
+    """SURVEY §8f row 4 (long files).  The reference keeps seven dense L x Kmax float64 arrays (60 s @48 kHz: 7 x 3.7 GB,
+    functions.py:159-160, :168-171).  Resident run: two arrays for the rank's range (7.3 GB).  Streaming run: a track
+    budget of 1 GB — the frames go in time blocks whose tracks are regenerated from the frame-centre records — must give
+    bit for bit the same SRER list, records and reconstruction as the resident run, with the peak device memory of the
+    engine's buffers lower by the tracks it no longer holds.  BASELINE config 5 (2,880,000 samples, 191,936 large frames,
+    Kmax 159), adaptations 0 and 1."""
+    import time
     import torch
+    from conftest import record_measurement
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
     from eaqhm_amd.synth import synth_speech_int16
     fs = 48000
     s = synth_speech_int16(60.0, fs) / 32768.0
     track = load_golden("prep_synth48k_60s.npz")["synth48k_60s_f0s_5ms"]
-    torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
-    base = torch.cuda.memory_allocated()
-    plan, eng, fin = _run(s, fs, track, 0)
-    torch.cuda.synchronize()
-    peak = torch.cuda.max_memory_allocated() - base
+    grid = prologue.resample_track(track, np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
     assert plan.n_frames == 191936 and plan.Kmax == 159
+    out = {}
+    for name, budget in (("resident", None), ("streaming", 1 << 30)):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        eng = DeviceAnalysis(s, s, plan, 160, 1, track_budget_bytes=budget)
+        t0 = time.time()
+        eng.run()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        peak = torch.cuda.max_memory_allocated() - base
+        fin = eng.final_arrays()
+        out[name] = dict(srer=[float(v) for v in eng.SRER], fin=fin, peak=peak, tracks=eng.track_bytes(),
+                         blocks=len(eng.blocks), seconds=dt)
+        del eng
+    res, stm = out["resident"], out["streaming"]
+    record_measurement("synth48k_60s_streaming", **{k: {q: v[q] for q in ("srer", "peak", "tracks", "blocks", "seconds")}
+                                                    for k, v in out.items()})
     dense = 2 * plan.Kmax * plan.L * 8
-    assert dense < peak < 12e9, "peak device memory of the run: %.2f GB (dense tracks %.2f GB)" % (peak / 1e9, dense / 1e9)
-    assert len(eng.SRER) == 1 and 50 < eng.SRER[0] < 70
-    d = s - fin["s_recon"]
-    assert abs(20 * np.log10(np.std(s) / np.std(d)) - eng.SRER[0]) < 1e-9
+    assert res["blocks"] == 1 and res["tracks"] >= dense and dense < res["peak"] < 12e9
+    assert stm["blocks"] >= 8 and stm["tracks"] <= (1 << 30)
+    assert stm["peak"] < res["peak"] - 0.8 * (dense - (1 << 30)), (stm["peak"], res["peak"])
+    assert stm["srer"] == res["srer"] and len(res["srer"]) == 2 and 50 < res["srer"][0] < 70
+    for k in res["fin"]:
+        assert np.array_equal(res["fin"][k], stm["fin"][k]), k
+    d = s - res["fin"]["s_recon"]
+    assert abs(20 * np.log10(np.std(s) / np.std(d)) - max(res["srer"])) < 1e-9

@@ -11,11 +11,15 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_golden, unpack_records
+from conftest import GOLDEN, load_golden, record_measurement, unpack_records
 
 pytestmark = pytest.mark.gpu
 
 TOL_AM_REL, TOL_FM_HZ, TOL_PH_RAD, TOL_SRER_DB = 1e-8, 1e-3, 1e-5, 1e-6
+# Full-band 48 kHz, adaptation >= 1 only: partials within ~200 Hz of Nyquist advance their phase by ~pi per
+# sample, and functions.py:375 takes fs/2pi * diff(unwrap(phase)) of them — each sample a coin flip between +fs/2 and
+# -fs/2 that a last-bit difference turns.  The reference's own SRER[1] moves by this much between NumPy builds.
+TOL_SRER_NYQUIST_DB = 1.0
 
 
 def wrap(d):
@@ -468,6 +472,13 @@ def test_48khz_large_frames():
     eng.run(on_adaptation=hook)
     assert abs(eng.SRER[0] - g["SRER"][0]) < TOL_SRER_DB
     assert len(eng.SRER) == 2 and eng.SRER[1] < eng.SRER[0]
+    record_measurement("synth48k_0p6s_fullband", srer_hip=[float(v) for v in eng.SRER],
+                       srer_reference=[float(v) for v in g["SRER"]])
+    # adaptation 1 of the full band (reference: 54.89 -> 18.50 dB): its value hangs on unwrap() decisions of partials
+    # whose phase advances by ~pi per sample (functions.py:375) — a coin flip per sample that rounding-level
+    # differences turn.  Stated tolerance for this 0.6 s input: TOL_SRER_NYQUIST_DB (measured distance: see
+    # profiles/r03_parity/measurements.json)
+    assert abs(eng.SRER[1] - g["SRER"][1]) < TOL_SRER_NYQUIST_DB
     ref = unpack_records(g, 0, with_fm=False)
     K = plan.Kmax
     am, ph = seen[0][:, :K], seen[0][:, 2 * K:3 * K]
@@ -477,6 +488,38 @@ def test_48khz_large_frames():
     strong = both & (ref["am"] > 1e-6 * ref["am"].max())      # the angle of a vanishing partial is ill-conditioned
     assert np.abs(wrap(ph[strong] - ref["ph"][strong])).max() <= TOL_PH_RAD
     assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9
+
+
+def test_48khz_fullband_2s_against_reference():
+    """Full-band 48 kHz at a size between the 0.6 s fixture and the 60 s bench workload: 2 s, maxAdpt=1, through the
+    reference itself (tests/golden/make_golden.py synth48k_2s; its own SWIPE' on these 2 s).  Adaptation 0 to the usual
+    1e-6 dB; adaptation 1 (reference: 57.63 -> 34.12 dB, the near-Nyquist collapse diluted by the length) within
+    TOL_SRER_NYQUIST_DB, plus the checksums of the frame-centre records of adaptation 0 and the decimated s_recon."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    g = load_golden("synth48k_2s_adpt1.npz")
+    fs = 48000
+    s = g["wav_int16"] / 32768.0
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, g["f0s_5ms"], frames, fstep, 15, 3, 32, 0)
+    sh = g["ls_shapes_iqhm"]
+    assert np.array_equal(2 * plan.frame_wl + 1, sh[:, 0]) and np.array_equal(2 * plan.frame_K + 1, sh[:, 1])
+    seen = {}
+    eng = DeviceAnalysis(s, s, plan, 160, 1)
+    eng.run(on_adaptation=lambda a, e: seen.update({a: e.records[0][:plan.No_ti].cpu().numpy().copy()}))
+    record_measurement("synth48k_2s_fullband", srer_hip=[float(v) for v in eng.SRER],
+                       srer_reference=[float(v) for v in g["SRER"]])
+    assert len(eng.SRER) == 2 and abs(eng.SRER[0] - g["SRER"][0]) < TOL_SRER_DB
+    assert abs(eng.SRER[1] - g["SRER"][1]) < TOL_SRER_NYQUIST_DB
+    K = plan.Kmax
+    rs, rec = g["recsum0"], seen[0]
+    assert abs(np.count_nonzero(rec[:, :K]) - int(rs[0])) <= 2
+    assert abs(rec[:, :K].sum() - rs[1]) <= 1e-7 * abs(rs[1]) and abs(rec[:, K:2 * K].sum() - rs[2]) <= 1e-7 * abs(rs[2])
+    assert abs(rec[:, 3 * K].sum() - rs[4]) <= 1e-7
+    fin = eng.final_arrays()                       # the kept result is adaptation 0's
+    dec = int(g["s_recon_decim"])
+    assert np.abs(fin["s_recon"][::dec] - g["s_recon_every"]).max() <= 1e-9
 
 
 # ----------------------------------------------------------------------------- hot-kernel raw LS solutions
@@ -664,6 +707,51 @@ def test_singular_system_raises_linalgerror(amd):
         amd.eaqhmLS_complexamps(s, np.ones((N, 4)), fm, np.hamming(N), 16000)
     a, b = amd.iqhmLS_complexamps(s, np.array([-200.0, 0.0, 200.0]), np.blackman(N), 16000)
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+
+
+def _normal_equations(s, am, fm, w, fs):
+    """functions.py:498-530 restated for a handful of columns: (R, arr) of the eaQHM least squares."""
+    N = len(s)
+    mid = (N - 1) // 2
+    n = np.arange(N) - mid
+    F = np.cumsum(fm, axis=0)
+    F = F - F[mid]
+    E2 = (1e-4 + am) / (am[mid] + 1e-4) * np.exp(2j * np.pi * F / fs)
+    E = np.concatenate((E2, n[:, None] * E2), axis=1)
+    Ew = E * w[:, None]
+    return Ew.conj().T @ Ew, Ew.conj().T @ (w * s)
+
+
+def test_ill_conditioned_but_nonsingular_system_is_solved_like_inv(amd):
+    """Where the line is drawn (ADVICE r2).  The reference's inv() returns whatever an ill-conditioned system gives;
+    the kernels raise only when the Cholesky factorisation BREAKS DOWN (pivot <= 2.5e-13 = order x eps of its diagonal
+    entry: exactly duplicated columns), not because a system is ill-conditioned.  Two columns 200 Hz and 200 Hz + df:
+    at df = 1 / 0.3 Hz the smallest pivots of the scaled system are 4e-9 / 2e-10 (cond(R) 1e10 - 1e12, four to six
+    orders beyond any frame of the fixtures): NumPy's inv() returns there and so must the kernel, with a residual of the
+    normal equations no worse than inv()'s; df = 0 still raises.  (A pivot placed exactly between the round-2 threshold
+    1e-12 and the breakdown threshold cannot be produced through this seam: the slope copy n*E2 of a near-duplicate
+    column squares the loss, and below ~1e-10 the last pivot is rounding noise in NumPy as well.)"""
+    rng = np.random.default_rng(3)
+    N, fs = 241, 16000
+    s = rng.standard_normal(N) * 0.1
+    w = np.hamming(N)
+    am = np.ones((N, 4))
+    seen = {}
+    for df in (1.0, 0.3):
+        fm = np.tile(np.array([-200.0, 0.0, 200.0, 200.0 + df]), (N, 1))
+        R, arr = _normal_equations(s, am, fm, w, fs)
+        x_ref = np.linalg.inv(R) @ arr                                   # functions.py:530 — returns, no exception
+        a, b = amd.eaqhmLS_complexamps(s, am, fm, w, fs)                 # must return too
+        x = np.concatenate((a.ravel(), b.ravel()))
+        assert np.all(np.isfinite(x))
+        res = np.linalg.norm(R @ x - arr) / np.linalg.norm(arr)
+        res_ref = np.linalg.norm(R @ x_ref - arr) / np.linalg.norm(arr)
+        seen["df_%g_hz" % df] = dict(cond=float(np.linalg.cond(R)), residual_kernel=float(res), residual_inv=float(res_ref),
+                                     rel_distance=float(np.abs(x - x_ref).max() / np.abs(x_ref).max()))
+        assert res <= 10 * res_ref + 1e-9
+    record_measurement("ill_conditioned_seam", **seen)
+    with pytest.raises(np.linalg.LinAlgError):
+        amd.eaqhmLS_complexamps(s, am, np.tile(np.array([-200.0, 0.0, 200.0, 200.0]), (N, 1)), w, fs)
 
 
 def test_singular_frame_in_batch_raises(amd, sa19_golden):

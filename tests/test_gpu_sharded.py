@@ -50,13 +50,13 @@ def _worker(rank, world, port, out_path, workload="sa19"):
 
     def hook(a, e):
         rec = e.records[0].clone()
-        e.shard.all_gather_rows(rec, plan.No_ti)        # test-only: complete rows of this adaptation
+        e.shard.all_gather_rows(rec, e.bounds)        # test-only: complete rows of this adaptation
         seen["rec%d" % a] = rec[:plan.No_ti].cpu().numpy()
 
     eng.run(on_adaptation=hook if workload != "sa19" else None)
     fin = eng.final_arrays()
     if rank == 0:
-        np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, bounds=np.array(eng.shard.bounds),
+        np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, bounds=np.array(eng.bounds),
                  **fin, **seen)
     dist.destroy_process_group()
 

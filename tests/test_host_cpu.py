@@ -88,15 +88,58 @@ def test_voiced_only_target_and_flags():
 
 
 def test_struct_packing_quirks(sa19_golden):
-    from eaqhm_amd.functions import _slot_array
+    from eaqhm_amd.functions import _slot_arrays
     from eaqhm_amd.structs import Deterministic, Frame
     d = Deterministic(ti=np.int64(5), isSpeech=True, isVoiced=True)
     assert d.ak == [] and d.a0 == [] and d.frange == [] and d.pk == [] and not hasattr(d, "amplitudes")
     assert "isVoiced" in str(d) and str(Frame(1, True, 0.5)).startswith("{")
-    arr = _slot_array(np.array([0, 2, 5]), np.array([1.5, 2.5, 3.5]))
+    vals = np.array([[1.5, 0, 2.5, 0, 0, 3.5, 0], [0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 9.0, 0, 0, 0]])
+    (arr, empty, one), = _slot_arrays(vals != 0, vals)
+    assert len(empty) == 0 and empty.dtype == object and len(one) == 4 and one[3][0] == 9.0 and one[0] == 0
     q = load_golden("unit_vectors.npz")["abi_dtype"]
     assert str(arr.dtype) == q[0] and str(arr.shape) == q[1] and type(arr[1]).__name__ == q[2]
     assert str(np.shape(arr[0])) == q[3] and arr[2][0] == 2.5 and arr[1] == 0
+
+
+def test_pack_results_fast_and_equal_to_the_cell_loop():
+    """functions.py:404-411 for a minute of speech: 64,000 instants x 59 slots, ~2 M active cells.  The
+    result must equal what the literal per-cell restatement of misc.py:65-93 builds (checked on a sample of instants)
+    and must not take the 15 s the per-cell Python loop took (bound stated for this 8-core container)."""
+    import time
+    from types import SimpleNamespace
+    from eaqhm_amd.functions import pack_results
+    rng = np.random.default_rng(5)
+    T, K = 64000, 59
+    am = rng.uniform(0.01, 1, (T, K)) * (rng.uniform(size=(T, K)) < 0.55)
+    am[:, 40:] *= rng.uniform(size=(T, 1)) < 0.3
+    analysed = np.ones(T, dtype=bool)
+    analysed[:32] = analysed[-32:] = False
+    analysed[1000:1010] = False
+    in_bounds = np.ones(T, dtype=bool)
+    in_bounds[:32] = in_bounds[-32:] = False
+    am[5000] = 0                                  # a voiced instant without any accepted harmonic
+    fin = dict(am=am, fm=am * 1000, pk=am - 0.5, a0=rng.standard_normal(T))
+    plan = SimpleNamespace(ti=np.arange(1, 15 * T, 15), No_ti=T, analysed=analysed, in_bounds=in_bounds)
+    t0 = time.time()
+    det = pack_results(plan, fin)
+    took = time.time() - t0
+    assert len(det) == T and took < 6.0, took
+    for i in (0, 31, 32, 999, 1005, 5000, 5001, 40000, T - 33, T - 1):
+        d = det[i]
+        assert type(d.ti) is np.int64 and d.ti == 15 * i
+        assert d.isSpeech == bool(in_bounds[i]) and d.isVoiced == bool(analysed[i])
+        if not analysed[i]:
+            assert d.a0 == [] and d.ak == [] and not hasattr(d, "amplitudes")
+            continue
+        assert type(d.a0) is np.float64 and d.a0 == fin["a0"][i] and d.ak == []
+        nz = np.flatnonzero(am[i])
+        for arr, src in ((d.amplitudes, am), (d.frange, fin["fm"]), (d.pk, fin["pk"])):
+            ref = np.zeros(int(nz[-1]) + 1 if len(nz) else 0, dtype=object)       # misc.py:89-93
+            for k in nz:
+                ref[k] = np.array([src[i, k]])
+            assert arr.dtype == object and len(arr) == len(ref)
+            for x, y in zip(arr, ref):
+                assert type(x) is type(y) and (x == y if isinstance(y, int) else (x.shape == (1,) and x[0] == y[0]))
 
 
 def test_sharding_ranges():
@@ -137,6 +180,90 @@ def test_cli_needs_the_gpu(tmp_path):
         cli.main([os.path.join(GOLDEN, "SA19.WAV"), "--gender", "female", "--max-adpt", "0", "--no-write"])
 
 
+def test_sharding_is_stateless_and_checks_its_ranges():
+    """One Sharding may serve several engines (run_interleaved): the ranges live on the engine, and a collective that is
+    handed ranges of another buffer refuses instead of exchanging the wrong rows."""
+    import torch
+    from eaqhm_amd.engine import Sharding
+    sh = Sharding(0, 2, group=object())          # (never reaches a collective: the check comes first)
+    assert not hasattr(sh, "bounds")
+    b = sh.balance(10, np.arange(10.0))
+    assert b == sh.balance(10, np.arange(10.0)) and b[0] == 0 and b[-1] == 10
+    with pytest.raises(ValueError):
+        sh.share_rows(torch.zeros(12, 3), b, 4)
+    with pytest.raises(ValueError):
+        sh.all_gather_rows(torch.zeros(10, 3), [0, 5])
+
+
+def test_srer_from_limbs_semantics():
+    """One SRER formula for every world size (engine.srer_from_limbs) with NumPy's semantics in the degenerate cases
+    the reference passes through silently (functions.py:388, :394: nan compares False, inf <= inf breaks)."""
+    from eaqhm_amd.engine import srer_from_limbs
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal(5000) * 1e-3
+    tot = sum(int(v) for v in np.trunc(d * 2.0 ** 60).astype(object))
+    tot2 = sum(int(v) for v in np.trunc(d * d * 2.0 ** 64).astype(object))
+
+    def limbs(v):
+        return [v & 0xffffffff, (v >> 32) & 0xffffffff, v >> 64]
+    L = limbs(tot) + limbs(tot2) + [0, 0]
+    want = 20 * np.log10(0.1 / np.std(d))
+    assert abs(srer_from_limbs(L, len(d), 0.1) - want) < 1e-9
+    # the sum of two ranks' limbs is the limbs of the sum: split the samples anywhere
+    h = 1234
+    def part(x):
+        return limbs(sum(int(v) for v in np.trunc(x * 2.0 ** 60).astype(object))) + \
+               limbs(sum(int(v) for v in np.trunc(x * x * 2.0 ** 64).astype(object))) + [0, 0]
+    two = [a + b for a, b in zip(part(d[:h]), part(d[h:]))]
+    assert srer_from_limbs(two, len(d), 0.1) == srer_from_limbs(L, len(d), 0.1)
+    assert np.isnan(srer_from_limbs(L[:6] + [1, 0], len(d), 0.1))            # a non-finite sample
+    assert srer_from_limbs([0] * 8, 100, 0.1) == np.inf                       # perfect reconstruction
+    assert srer_from_limbs(L, len(d), 0.0) == -np.inf                         # silent target
+    assert np.isnan(srer_from_limbs([0] * 8, 100, 0.0))
+    assert not (np.float64(np.nan) <= np.float64(1.0)) and np.float64(np.inf) <= np.float64(np.inf)
+
+
+def test_time_block_streaming_matches_resident_run_host_logic():
+    """SURVEY §8f row 4 (long files): with a track budget the frames are worked off in time blocks whose dense tracks
+    are regenerated from the records; the host logic (block plan, windows, seeding flags, stop rule) with the oracle
+    stand-in must reproduce the resident run exactly, and hold no more track cells than the budget allows."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_backend import OracleBackend
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.synth import synth_speech_int16
+    torch.set_num_threads(2)
+    fs = 16000
+    x = synth_speech_int16(0.72, fs).copy()
+    x[5200:6100] = 0                                  # digital silence: empty-row seeding inside one block's halo
+    s = x / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    grid = prologue.resample_track(np.column_stack([t, _pitch_profile(t, "true")]),
+                                   np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 480)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    res = DeviceAnalysis(s, s, plan, 100, 2, ctx=OracleBackend())
+    res.run()
+    budget = DeviceAnalysis.TRACK_BYTES_PER_CELL * plan.Kmax * 1500
+    blk = DeviceAnalysis(s, s, plan, 100, 2, ctx=OracleBackend(), track_budget_bytes=budget)
+    assert len(blk.blocks) >= 4 and blk.track_bytes() <= budget < res.track_bytes()
+    assert blk.blocks[0][0] == 0 and blk.blocks[-1][1] == blk.nf
+    assert all(a[1] == b[0] for a, b in zip(blk.blocks, blk.blocks[1:]))
+    c = plan.frame_c
+    for fa, fb, lo, hi in blk.blocks:                # every window of the block (+ the sample before) is resident
+        assert lo <= c[fa] - plan.frame_wl[fa] - 1 or lo == 0
+        assert c[fb - 1] + plan.frame_wl[fb - 1] < hi and (hi - lo) <= 1500
+    blk.run()
+    assert [float(v) for v in blk.SRER] == [float(v) for v in res.SRER]
+    a, b = res.final_arrays(), blk.final_arrays()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        DeviceAnalysis(s, s, plan, 100, 2, ctx=OracleBackend(), track_budget_bytes=1000)
+
+
 def _pitch_profile(t, profile):
     f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
     if profile == "step":      # a pitch track that drops to 0.7 of the true pitch half way: the second half's frames
@@ -170,7 +297,7 @@ def _sharded_worker(rank, world, port, out_path, profile="true"):
     eng.run()
     fin = eng.final_arrays()
     if rank == 0:
-        np.savez(out_path, SRER=np.array(eng.SRER), n_frames_rank0=eng.n_ls_frames, bounds=np.array(eng.shard.bounds),
+        np.savez(out_path, SRER=np.array(eng.SRER), n_frames_rank0=eng.n_ls_frames, bounds=np.array(eng.bounds),
                  **fin)
     dist.destroy_process_group()
 

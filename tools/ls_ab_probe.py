@@ -32,7 +32,7 @@ def time_ls(ctx, reps=(2 if fs > 16000 else 5)):
         for r in range(reps + 1):
             if r == 1:
                 ev[0].record()
-            ctx.ls_batch(a, eng.s, p.L, p.fs, eng.am_cur, eng.fm_cur, p.Kmax, eng.frame_inst, eng.frame_c, eng.frame_wl,
+            ctx.ls_batch(a, eng.s, p.L, p.fs, eng.am_cur, eng.fm_cur, eng.track_t0, eng.track_len, p.Kmax, eng.frame_inst, eng.frame_c, eng.frame_wl,
                          eng.frame_f0, eng.frame_K, eng.ncol, eng.cols, eng.seeded, eng.any_seed, eng.nf, p.wl_max, a,
                          p.f0_stale, eng.f0min, eng.records[0], None, None)
         ev[1].record()

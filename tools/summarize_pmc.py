@@ -32,6 +32,9 @@ for kern, d in res.items():
                 d[k + "_share_of_wave_cycles"] = d[k + "_mean_per_launch"] / wave
     if busy and mfma:
         d["mfma_busy_over_sq_busy"] = mfma / busy
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+res["source_hash"] = bench.source_hash()      # bench.py withholds roofline.traffic when the tree's hash differs
 res["git_head"] = head
 res["workload"] = workload
 res["_note"] = ("rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), bench.py --workload %s --steps 1 "
