@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 
 TOL_AM_REL, TOL_FM_HZ, TOL_PH_RAD, TOL_SRER_DB = 1e-8, 1e-3, 1e-5, 1e-6
 # Full-band 48 kHz, adaptation >= 1 only: partials within ~200 Hz of Nyquist advance their phase by ~pi per
-# sample, and functions.py:375 takes fs/2pi * diff(unwrap(phase)) of them — each sample a coin flip between +fs/2 and
-# -fs/2 that a last-bit difference turns.  The reference's own SRER[1] moves by this much between NumPy builds.
-TOL_SRER_NYQUIST_DB = 1.0
+# sample, and functions.py:375 takes fs/2pi * diff(unwrap(phase)) of them — a decision per sample that a last-bit
+# difference can turn.  Measured on MI355X against the reference (profiles/r03_parity/parity_measurements.json): 1.6e-5 dB
+# on the 0.6 s input (18.497426 vs 18.497410), 2.8e-7 dB on the 2 s input (34.1187839 vs 34.1187842; the NumPy oracle is
+# 1.6e-9 dB from the reference there).  Stated tolerance, with margin for other inputs of this kind:
+TOL_SRER_NYQUIST_DB = 1e-3
 
 
 def wrap(d):
