@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--workload", default="synth16k_60s", choices=WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-stages", action="store_true", help="skip the one-off timing of SWIPE' / VUV / packing")
+    ap.add_argument("--track-budget-mb", type=float, default=0.0,
+                    help="time-block streaming of the dense tracks under this budget (0: resident) — SURVEY 8f row 4")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -292,7 +294,8 @@ def main():
         shard = HostStaged(rank, world, dist.group.WORLD)
     else:
         shard = Sharding(rank, world, dist.group.WORLD if use_dist else None)
-    eng = DeviceAnalysis(s, s, plan, 160, args.max_adpt, device_index=local, shard=shard)
+    eng = DeviceAnalysis(s, s, plan, 160, args.max_adpt, device_index=local, shard=shard,
+                         track_budget_bytes=int(args.track_budget_mb * 2 ** 20) if args.track_budget_mb > 0 else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -400,7 +403,7 @@ def main():
                    + "; pitch grid = fixture from the reference's SWIPE'",
            "config": {"workload": "%s_female_maxAdpt%d" % (args.workload, args.max_adpt), "samples": int(plan.L),
                       "fs": int(fs), "ls_frames_per_adaptation": int(plan.n_frames), "adaptations_executed": n_adpt,
-                      "Kmax": int(plan.Kmax),
+                      "Kmax": int(plan.Kmax), "track_bytes": int(eng.track_bytes()), "time_blocks": len(eng.blocks),
                       "parallelism": "instants sharded x%d by LS cost; boundary records all-gathered per adaptation"
                                      % world},
            "final_srer_db": max(srer), "srer_db": srer, "roofline": roofline}

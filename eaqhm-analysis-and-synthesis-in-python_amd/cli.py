@@ -24,6 +24,8 @@ def main(argv=None):
     ap.add_argument("--fc", type=int, default=0)
     ap.add_argument("--partials", type=int, default=0)
     ap.add_argument("--no-write", action="store_true")
+    ap.add_argument("--track-budget-mb", type=float, default=0.0,
+                    help="long files: device memory for the dense tracks; 0 = keep them resident for the whole file")
     a = ap.parse_args(argv)
     gender = a.gender
     if "," in gender:
@@ -32,7 +34,8 @@ def main(argv=None):
     s_recon, srer, det, t = eaQHMAnalysisAndSynthesis(
         a.wav, gender, step=a.step, maxAdpt=a.max_adpt, pitchPeriods=a.pitch_periods,
         analysisWindow=a.analysis_window, fullWaveform=not a.voiced_only, fc=a.fc, partials=a.partials,
-        printPrompts=True, loadingScreen=False)
+        printPrompts=True, loadingScreen=False,
+        track_budget_bytes=int(a.track_budget_mb * 2 ** 20) if a.track_budget_mb > 0 else None)
     if not a.no_write:
         fs, _ = wavfile.read(a.wav)
         out = a.wav[:len(a.wav) - 4] + "_reconstructed.wav"

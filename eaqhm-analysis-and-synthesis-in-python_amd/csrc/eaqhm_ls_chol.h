@@ -176,8 +176,12 @@ __device__ inline bool spin_until(int* flag, int target) {
   return false;
 }
 
-__device__ __attribute__((always_inline)) inline void diag_D(d4 R, d4 I, double* post, int* flag, int flag_base,
-                                                              double* dump, double* LdR, double* LdI, bool want_L) {
+//   postB    LDS: [7 steps][64 lanes][re-plane operand, im-plane operand]  the second MFMA operands of each elimination
+//            step, as this wave uses them itself: panel_follow applies the same steps to the panel tiles of the column
+#define DGB_DOUBLES (7 * 64 * 2)
+__device__ __attribute__((always_inline)) inline void diag_D(d4 R, d4 I, double* post, double* postB, int* flag,
+                                                              int flag_base, double* dump, double* LdR, double* LdI,
+                                                              bool want_L) {
   const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
   const bool hi = lq >= 2, odd = (lq & 1) != 0;   // which of (c1, c2) / (re, im) this lane's operand entry is
   const double sg = hi ? 1.0 : -1.0;
@@ -216,6 +220,7 @@ __device__ __attribute__((always_inline)) inline void diag_D(d4 R, d4 I, double*
       asel = (lcol >= j + 2) ? asel : 0.0;
       const double rr_ = fma(u, Xr, -fma(vr, Yr, -(vi * Yi))), ri_ = fma(u, Xi, -fma(vr, Yi, vi * Yr));
       const double bre = odd ? ri_ : -rr_, bim = odd ? -rr_ : -ri_;
+      if (postB) { postB[(st * 64 + lane) * 2] = bre; postB[(st * 64 + lane) * 2 + 1] = bim; }
       R = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bre, R, 0, 0, 0);
       I = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bim, I, 0, 0, 0);
     }
@@ -309,6 +314,79 @@ __device__ __attribute__((always_inline)) inline void diag_Z(const double* post,
     const double wr = (ZR[r] - (lr * wpr - li * wpi)) * io, wi = (ZI[r] - (lr * wpi + li * wpr)) * io;
     WtR[lcol * TL_LD + row] = wr;
     WtI[lcol * TL_LD + row] = -wi;
+  }
+}
+
+
+// ---- panel tiles without the inverse: a third role in the pipeline ------------------------------------------------
+// A panel tile A = T[P][jb] (P > jb) becomes L[P][jb] = A L_jj^-H.  Instead of waiting for W = L_jj^-1 and multiplying
+// (two workgroup barriers and the tail of diag_Z on the critical path of every tile row), the tile's owner APPLIES THE
+// ELIMINATION STEPS of the diagonal tile to it as diag_D posts them: step (j, j+1) is
+//     A[i][k] -= A[i][j] c1[k] + A[i][j+1] c2[k],   k >= j+2,
+// with exactly the (c1, c2) operand diag_D uses on its own tile (postB); the first operand is the tile's own column pair
+// (j, j+1), handed to the MFMA operand lanes through 64 doubles of wave-private LDS.  What is left are the raw columns
+// of each pivot block, finished with the block's 2x2 Cholesky factor [[l11, 0], [l21, l22]]:
+//     L[:, j] = A[:, j] / l11,   L[:, j+1] = (A[:, j+1] - L[:, j] conj(l21)) / l22        (lane ^ 1 holds the partner column).
+// The wave may arrive late (after its trailing updates): the posts of all steps stay in LDS until the stage ends.
+//   tab  64 doubles, fac 64 doubles of wave-private LDS
+__device__ inline void panel_block_factors(const double* post, double* fac) {   // lane b <-> pivot block b
+  const int lane = threadIdx.x & 63, b = lane & 7, j = 2 * b;
+  const double* rows = post + b * 64;
+  double p = rows[2 * j];
+  const double qr = rows[2 * (j + 1)], qi = -rows[2 * (j + 1) + 1], r = rows[32 + 2 * (j + 1)];   // q = T[j+1][j]
+  p = (p > 0.0) ? p : 1.0;
+  const double i11 = rsqrt_nr(p);
+  const double l21r = qr * i11, l21i = qi * i11;
+  double s22 = r - (l21r * l21r + l21i * l21i);
+  s22 = (s22 > 0.0) ? s22 : 1.0;
+  const double i22 = rsqrt_nr(s22);
+  // per column of the tile: {iota, lambda re, lambda im, kappa};  first column of a block {i11, 0, 0, 0}, second {i22, l21, i11}
+  fac[j * 4 + 0] = i11; fac[j * 4 + 1] = 0.0; fac[j * 4 + 2] = 0.0; fac[j * 4 + 3] = 0.0;
+  fac[j * 4 + 4] = i22; fac[j * 4 + 5] = l21r; fac[j * 4 + 6] = l21i; fac[j * 4 + 7] = i11;
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __attribute__((always_inline)) inline bool panel_follow(d4& R, d4& I, const double* postB, int* flag,
+                                                                    int flag_base, double* tab) {
+  const int lane = threadIdx.x & 63, lq = lane >> 4, lcol = lane & 15;
+  bool ok = true;
+#pragma clang loop unroll(disable)
+  for (int st = 0; st < 7; ++st) {
+    const int j = 2 * st;
+    // the tile's columns j, j+1 (lanes lcol = j, j+1; rows lq + 4 r) -> tab[row][column][re, im]
+    if ((lcol >> 1) == st) {
+      const int cb = (lcol & 1) * 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tab[(lq + 4 * r) * 4 + cb] = R[r];
+        tab[(lq + 4 * r) * 4 + cb + 1] = I[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // first operand: row i = lcol, k-slot lq = (a1 re, a1 im, a2 re, a2 im)
+    const double asel = tab[lcol * 4 + lq];
+    if (!spin_until(flag, flag_base + st + 1)) ok = false;
+    const double bre = postB[(st * 64 + lane) * 2], bim = postB[(st * 64 + lane) * 2 + 1];
+    R = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bre, R, 0, 0, 0);
+    I = __builtin_amdgcn_mfma_f64_16x16x4f64(asel, bim, I, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();   // (tab is rewritten by the next step)
+    (void)j;
+  }
+  return ok;
+}
+// finish the columns of a followed tile with the pivot blocks' own factors (panel_block_factors)
+__device__ __attribute__((always_inline)) inline void panel_finish(d4& R, d4& I, const double* fac) {
+  const int lcol = threadIdx.x & 15;
+  const double io = fac[lcol * 4], lr = fac[lcol * 4 + 1], li = fac[lcol * 4 + 2], ka = fac[lcol * 4 + 3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // partner column (lcol ^ 1) of the same row sits in lane ^ 1, same register
+    const double pr = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(R[r]), 0x041F),
+                                       __builtin_amdgcn_ds_swizzle(__double2loint(R[r]), 0x041F));
+    const double pi = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(I[r]), 0x041F),
+                                       __builtin_amdgcn_ds_swizzle(__double2loint(I[r]), 0x041F));
+    const double wpr = ka * pr, wpi = ka * pi;                  // L[:, j] of the block (zero for a first column)
+    const double xr = (R[r] - (wpr * lr + wpi * li)) * io, xi = (I[r] - (wpi * lr - wpr * li)) * io;
+    R[r] = xr; I[r] = xi;
   }
 }
 

@@ -341,6 +341,115 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         for (int r = 0; r < 4; ++r)
           if (lq + 4 * r == lcol) dorig[16 * tP[sl] + lcol] = accR[sl][r];
       }
+#ifdef EAQHM_PANEL_FOLLOW   /* measured slower: kept as an experiment build */
+      // Right-looking tile Cholesky.  Stage jb, two workgroup barriers:
+      //   every wave   brings its tiles of tile column jb up to date with panel jb-1 (the diagonal tile first)
+      //   owner wave   factorises the diagonal tile (diag_D: 2x2 block pivots on the matrix cores) and posts every step
+      //   a neighbour  follows one step behind and builds the inverse W (diag_Z: needed by the back substitution)
+      //   the others   apply the posted steps to their panel tiles themselves (panel_follow) — after their trailing
+      //                updates with panel jb-1, so they normally find all the posts waiting — no wave waits for W
+      //   barrier (every read of panel jb-1 done) — panel jb published — barrier
+      double* post = Dc;                 // what diag_D posts for diag_Z (Dc and Zc are contiguous: 1088 doubles)
+      double* dumpD = Dc + DGP_DOUBLES;  // [128] dump slots of diag_D
+      double* zs = dumpD + 128;          // [256] row exchange, dump slots and row factors of diag_Z
+      int* dflag = (int*)(zs + 256);     // step counter of the diagonal pipeline
+      double* postB = win;               // [DGB_DOUBLES] second operands of the steps (the windows are dead by now)
+      double* ftab = sig + wave * 128;   // [64] column exchange + [64] block factors of this wave (panel_follow)
+      if (tid == 0) *dflag = 0;          // (region U held the last basis chunk until the barrier that ended the Gramian)
+      __syncthreads();
+#define TRAILING_UPDATE(sl)                                                                         \
+  {                                                                                                 \
+    const double* ar = PanR + tP[sl] * TL_TILE;                                                     \
+    const double* ai = PanI + tP[sl] * TL_TILE;                                                     \
+    const double* br = PanR + tQ[sl] * TL_TILE;                                                     \
+    const double* bi = PanI + tQ[sl] * TL_TILE;                                                     \
+    /* T -= L_P L_Q^H, three real products: P1 = re re', P2 = im im', P3 = (re+im)(im'-re');   */   \
+    /* Re -= P1 + P2,  Im += P3 + P1 - P2  (P3 accumulates straight into the imaginary part)   */   \
+    d4 p1 = (d4){0, 0, 0, 0}, p2 = (d4){0, 0, 0, 0};                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                              \
+      const int o = (4 * ks + lq) * TL_LD + lcol;                                                   \
+      const double aR = ar[o], aI = ai[o], lR = br[o], lI = bi[o];                                  \
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aR, lR, p1, 0, 0, 0);                               \
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI, lI, p2, 0, 0, 0);                               \
+      accI[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR + aI, lI - lR, accI[sl], 0, 0, 0);         \
+    }                                                                                               \
+    accR[sl] = accR[sl] - (p1 + p2);                                                                \
+    accI[sl] = accI[sl] + (p1 - p2);                                                                \
+  }
+      for (int jb = 0; jb < nt; ++jb) {
+        const int wD = (jb * nt - jb * (jb - 1) / 2) % TL_CW;   // owner of the diagonal tile (column-major numbering)
+        const int wZ = wD ^ 1;                                   // builds the inverse
+        const bool isD = wave == wD, isZ = wave == wZ;
+        // ---- the diagonal tile
+        if (isD) {
+          d4 Rt = (d4){0, 0, 0, 0}, It = (d4){0, 0, 0, 0};
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) {
+            if (!live[sl] || tP[sl] != jb || tQ[sl] != jb) continue;
+            if (jb > 0) TRAILING_UPDATE(sl)
+            Rt = accR[sl]; It = accI[sl];
+          }
+          diag_D(Rt, It, post, postB, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
+        }
+        // ---- panel tiles of this column: current with panel jb-1 first
+        if (jb > 0) {
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) {
+            if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
+            TRAILING_UPDATE(sl)
+          }
+        }
+        if (isZ)   // real unknowns: every position but, in the last tile, the signal column `is` and the padding behind it
+          diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
+                 (jb == nt - 1) ? is : 16, uni(A.fault));
+        STAMP(10);
+        // ---- the rest of the trailing matrix
+        if (jb > 0) {
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) {
+            if (!live[sl] || tQ[sl] <= jb) continue;
+            TRAILING_UPDATE(sl)
+          }
+        }
+        STAMP(8);
+        // ---- panel tiles (P > jb, Q == jb): the posted elimination steps, then the pivot blocks' factors
+        if (jb < nt - 1) {
+          bool any = false, ok = true;
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) any = any || (live[sl] && tQ[sl] == jb && tP[sl] != jb);
+          if (any) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+              if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
+              ok = panel_follow(accR[sl], accI[sl], postB, dflag, 16 * jb, ftab) && ok;
+            }
+            if (!spin_until(dflag, 16 * jb + 8)) ok = false;   // (the last step's rows hold the last pivot block)
+            panel_block_factors(post, ftab + 64);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+              if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
+              panel_finish(accR[sl], accI[sl], ftab + 64);   // the L tile stays here for the back substitution
+            }
+            if (!ok && lane == 0) atomicAdd(uni(A.fault) + 1, 1);
+          }
+        }
+        STAMP(7);
+        __syncthreads();  // (A) every read of panel jb-1 done, every tile of column jb finished
+        STAMP(6);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          if (!live[sl] || tQ[sl] != jb || tP[sl] == jb) continue;
+          double* tr = PanR + tP[sl] * TL_TILE;
+          double* ti = PanI + tP[sl] * TL_TILE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // L[row = lq+4r][k = lcol] -> Pan[k][row]
+            tr[lcol * TL_LD + lq + 4 * r] = accR[sl][r];
+            ti[lcol * TL_LD + lq + 4 * r] = accI[sl][r];
+          }
+        }
+        __syncthreads();  // (C) panel jb published
+      }
+#else
       // Right-looking tile Cholesky with look-ahead.  Stage jb: the trailing update with panel jb-1 — the diagonal tile
       // (jb, jb) first, whose owner then factorises and inverts it on its own (diag_wave: one wave, matrix cores, no
       // workgroup barrier) while the other waves are still in their updates — barrier — panel jb — barrier.
@@ -382,7 +491,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         // real unknowns: every position but, in the last tile, the signal column `is` and the padding behind it
 #ifndef EAQHM_EXPERIMENT_NODIAG   /* (timing experiment: what a frame costs without the diagonal steps; wrong results) */
         if (mine)
-          diag_D(Rt, It, post, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
+          diag_D(Rt, It, post, nullptr, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
         else if (wave == (((jb * nt - jb * (jb - 1) / 2) % TL_CW) ^ 1))   // the owner's neighbour builds the inverse
           diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
                  (jb == nt - 1) ? is : 16, uni(A.fault));
@@ -436,6 +545,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         STAMP(7);
         __syncthreads();  // (C) panel jb published
       }
+#endif
 #undef TRAILING_UPDATE
       __syncthreads();  // end of factorisation
       STAMP(3);

@@ -66,7 +66,7 @@ def _slot_arrays(active, *fields):
 
 
 def _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc, partials,
-             pitch_track, device_index):
+             pitch_track, device_index, track_budget_bytes=None):
     """functions.py:86-146: everything before the adaptation loop -> (plan, engine)."""
     fs, s = prologue.read_signal(speechFile, fc)                                 # functions.py:86-91
     length = len(s)
@@ -83,14 +83,16 @@ def _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fu
     else:
         target = prologue.voiced_only_target(s, frames, frame_step)              # functions.py:127-138
     plan = FramePlan(length, fs, f0_grid, frames, frame_step, step, pitchPeriods, analysisWindow, partials)
-    return plan, DeviceAnalysis(s, target, plan, f0min, maxAdpt, device_index=device_index)
+    return plan, DeviceAnalysis(s, target, plan, f0min, maxAdpt, device_index=device_index,
+                                track_budget_bytes=track_budget_bytes)
 
 
 def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', step: int = 15,
                               maxAdpt: int = 10, pitchPeriods: int = 3, analysisWindow: int = 32,
                               fullWaveform: bool = True, fc: int = 0, partials: int = 0,
                               printPrompts: bool = True, loadingScreen: bool = True, *,
-                              pitch_track=None, device_index: int = 0, _return_engine: bool = False):
+                              pitch_track=None, device_index: int = 0, track_budget_bytes=None,
+                              _return_engine: bool = False):
     """Adaptive quasi-harmonic analysis/resynthesis of a mono 16-bit .wav on an MI355X.
 
     Parameters and returns: exactly those of the reference (functions.py:38-82).  `loadingScreen` is
@@ -100,10 +102,14 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
       pitch_track   (T, >=2) array [time s, f0 Hz, ...] used instead of running SWIPE' — either the
                     1 ms track swipep() returns or an already resampled 5 ms grid
       device_index  which GPU of this process to use
+      track_budget_bytes  long files: bytes the dense am/fm tracks (and their zero counts) may occupy on the device.
+                    None keeps them resident for the whole file (the reference keeps seven (L, Kmax) arrays,
+                    functions.py:159-171); with a budget the frames are worked off in time blocks whose tracks are
+                    regenerated from the frame-centre records — same results, bit for bit
     """
     start = time()
     plan, eng = _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc,
-                         partials, pitch_track, device_index)
+                         partials, pitch_track, device_index, track_budget_bytes)
 
     state = {"t": time()}
 

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_path, workload="sa19"):
+def _worker(rank, world, port, out_path, workload="sa19", budget=None):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -45,7 +45,8 @@ def _worker(rank, world, port, out_path, workload="sa19"):
     frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
     prologue.apply_full_waveform(frames, len(s), 480)
     plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
-    eng = DeviceAnalysis(s, s, plan, 160, max_adpt, shard=HostStaged(rank, world, dist.group.WORLD))
+    eng = DeviceAnalysis(s, s, plan, 160, max_adpt, shard=HostStaged(rank, world, dist.group.WORLD),
+                         track_budget_bytes=budget)
     seen = {}
 
     def hook(a, e):
@@ -57,7 +58,7 @@ def _worker(rank, world, port, out_path, workload="sa19"):
     fin = eng.final_arrays()
     if rank == 0:
         np.savez(out_path, SRER=np.array(eng.SRER), frames_rank0=eng.n_ls_frames, bounds=np.array(eng.bounds),
-                 **fin, **seen)
+                 blocks=len(eng.blocks), **fin, **seen)
     dist.destroy_process_group()
 
 
@@ -92,5 +93,20 @@ def test_two_ranks_seeding_across_the_rank_boundary(tmp_path):
     b = got["bounds"]
     z0, z1 = g["zero_span"] // 15
     assert z0 + 20 < b[1] < z1 - 20, "rank boundary %d not inside the silent span %d..%d" % (b[1], z0, z1)
+    seen = {a: got["rec%d" % a] for a in range(4)}
+    check_seeding_result(g, got["SRER"], seen, {k: got[k] for k in ("am", "fm", "pk", "a0", "s_recon")})
+
+
+def test_two_ranks_with_time_block_streaming(tmp_path):
+    """Ranks AND time blocks: the seeding signal on two ranks, each working its range off in blocks of <= 1500 samples
+    of tracks (the silent span crosses both the rank boundary and block boundaries).  Same checks as the resident run."""
+    import torch.multiprocessing as mp
+    from test_gpu_parity import check_seeding_result
+    g = load_golden("seed16k_1p2s_adpt6.npz")
+    out = str(tmp_path / "r0.npz")
+    budget = 18 * 59 * 1500            # DeviceAnalysis.TRACK_BYTES_PER_CELL * Kmax * samples
+    mp.spawn(_worker, args=(2, 29000 + os.getpid() % 300, out, "seed", budget), nprocs=2, join=True)
+    got = np.load(out)
+    assert int(got["blocks"]) >= 4
     seen = {a: got["rec%d" % a] for a in range(4)}
     check_seeding_result(g, got["SRER"], seen, {k: got[k] for k in ("am", "fm", "pk", "a0", "s_recon")})
