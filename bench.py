@@ -390,6 +390,12 @@ def main():
                 "source_hash": src,
                 "launches_timed": len(ls_ms),
                 "post_stage_ms_mean": float(np.mean(post_ms)) if post_ms else None,
+                # the bandwidth-type stage (spline + interpolation + synthesis + SRER, functions.py:337-388):
+                # algorithmic bytes = records read (1+3 Kmax) 8 No_ti + tracks and reconstruction written (1+2 Kmax) 8 L
+                "post_stage_hbm": (lambda b, t: {"bound": "hbm", "algorithmic_bytes": b, "achieved_GBps": b / t / 1e6,
+                                                 "peak_GBps": 8000.0, "frac": b / t / 1e6 / 8000.0})(
+                    float((1 + 3 * plan.Kmax) * 8 * plan.No_ti + (1 + 2 * plan.Kmax) * 8 * (eng.t_hi - eng.t_lo)),
+                    float(np.mean(post_ms))) if post_ms else None,
                 "all_gather_ms_mean": float(np.mean(gather_ms)) if gather_ms else None,
                 "ls_ms_mean_per_rank": [float(v) for v in allr[:, 4]],
                 "ls_frames_per_rank": [int(v) for v in allr[:, 5]],
