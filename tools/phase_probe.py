@@ -15,7 +15,9 @@ names = ["setup + slot preparation", "build: barrier wait", "contraction (a>=1) 
          "back substitution", "record", "wait at barrier A (the diagonal pipeline of another wave)", "panel (X = T W^H)",
          "trailing update (own tiles)", "-", "barrier C wait + next diagonal tile's update + diagonal role (when wave 0 has one)",
          "-", "build: basis rows (wave 0)"]
-tot = sum(d[:13])
-for n, v in zip(names, d):
+tot = sum(d[:9]) + d[10] + d[12]
+for n, v in zip(names, d[:13]):
     print("%-90s %14d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
+if d[13]:
+    print("diag_D: %d tiles, %.0f cycles inside per tile, %.0f cycles from the end of one to the start of the next" % (d[13], d[9] / d[13], d[11] / max(d[14], 1)))
 print("workload", wl, "frames", eng.n_ls_frames, "cycles/frame", tot / max(1, eng.n_ls_frames), "SRER", [float(v) for v in eng.SRER])
