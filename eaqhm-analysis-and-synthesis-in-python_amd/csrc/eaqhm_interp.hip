@@ -419,7 +419,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
 #pragma unroll
     for (int q = 0; q < ES_LIMBS - 1; ++q) {
       for (int o = 32; o > 0; o >>= 1) e[q] += __shfl_xor(e[q], o);
-      if (tid == 0) A.partials[ES_LIMBS * (size_t)blockIdx.x + q] = e[q];
+      if (tid == 0) A.partials[(size_t)q * gridDim.x + blockIdx.x] = e[q];   // [limb][block]: the reduction reads coalesced
     }
   }
 }
@@ -429,13 +429,13 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
 //                   SRER itself from the limbs (one formula for every world size and block count)
 //   sums_out[4..5]  LS faults / stalled diagonal pipelines since the last read (both counters are cleared)
 //   sums_out[8..15] the limbs as int64 bit patterns: what ranks and time blocks add up
-extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const long long* partials, long long nblocks, double n,
+extern "C" __global__ void __launch_bounds__(1024) eaqhm_srer_kernel(const long long* partials, long long nblocks, double n,
                                                                     double std_det, double* sums_out, int* faults) {
-  __shared__ long long red[4][ES_LIMBS];
+  __shared__ long long red[16][ES_LIMBS];
   long long e[ES_LIMBS - 1] = {0, 0, 0, 0, 0, 0, 0};
   for (long long b = threadIdx.x; b < nblocks; b += blockDim.x)
 #pragma unroll
-    for (int q = 0; q < ES_LIMBS - 1; ++q) e[q] += partials[ES_LIMBS * b + q];
+    for (int q = 0; q < ES_LIMBS - 1; ++q) e[q] += partials[(size_t)q * nblocks + b];
 #pragma unroll
   for (int q = 0; q < ES_LIMBS - 1; ++q) {
     for (int o = 32; o > 0; o >>= 1) e[q] += __shfl_xor(e[q], o);
@@ -444,7 +444,11 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_srer_kernel(const long l
   __syncthreads();
   if (threadIdx.x == 0) {
     long long* lim = (long long*)(sums_out + 8);
-    for (int q = 0; q < ES_LIMBS - 1; ++q) { e[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q]; lim[q] = e[q]; }
+    for (int q = 0; q < ES_LIMBS - 1; ++q) {
+      e[q] = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) e[q] += red[w][q];
+      lim[q] = e[q];
+    }
     lim[ES_LIMBS - 1] = 0;
     const double a = ((double)e[2] * 0x1p64 + (double)e[1] * 0x1p32 + (double)e[0]) * 0x1p-60;
     const double b = ((double)e[5] * 0x1p64 + (double)e[4] * 0x1p32 + (double)e[3]) * 0x1p-64;
@@ -573,7 +577,7 @@ extern "C" int eaqhm_eval_synth(eaqhm_ctx* ctx, const double* records, const uin
   hipLaunchKernelGGL(eaqhm_eval_kernel, dim3((unsigned)nblocks), dim3(256), lds_bytes, ctx->stream, A, TBS, NK, NR);
   HIP_TRY(ctx, hipGetLastError());
   if (!synth) return EAQHM_OK;
-  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(256), 0, ctx->stream, (const long long*)partials, nblocks,
+  hipLaunchKernelGGL(eaqhm_srer_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const long long*)partials, nblocks,
                      (double)(s_hi - s_lo), std_det, sums_out, ctx->faults);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;

@@ -26,6 +26,7 @@ Usage:
     python tests/golden/make_golden.py prep48k60       # pre-processing of the 60 s @48 kHz bench workload
     python tests/golden/make_golden.py synth16k_60s    # the headline workload at full size: 60 s @16 kHz, maxAdpt=5 (~1 h, ~5 GB)
     python tests/golden/make_golden.py synth48k_2s     # 2 s synthetic @48 kHz full band, maxAdpt=1 (~10 min)
+    python tests/golden/make_golden.py male16k_2s      # 2 s of a low voice @16 kHz (`male`), maxAdpt=2: large frames
 """
 import os
 import sys
@@ -419,6 +420,23 @@ def job_synth48k_2s():
     save("synth48k_2s_adpt1.npz", o)
 
 
+def job_male16k_2s():
+    """A low voice at 16 kHz: the generator's 1 s @32 kHz read as 2 s @16 kHz (every frequency halves: f0 85-135 Hz, 57
+    partials up to 7.7 kHz), gender `male` (70-180 Hz).  Frames of up to 185 basis columns and windows of up to 565
+    samples: beyond the on-chip tile kernel, i.e. the large-frame kernels at 16 kHz, adaptations 0-2, through the
+    reference itself."""
+    fs = 16000
+    x = synth_speech_int16(1.0, 32000)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(ls_frames_iqhm=(300,), ls_frames_eaqhm=(300, 1500), dense_adpts=(), rec_adpts=(1,), ls_outputs_only=True)
+    o = run_reference(wav, "male", cap, maxAdpt=2)
+    o["wav_int16"] = x
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    os.unlink(wav)
+    save("male16k_2s_adpt2.npz", o)
+
+
 def job_prep48k60():
     xs = synth_speech_int16(60.0, 48000)
     r = prep_only(xs, 48000, "female")
@@ -507,6 +525,7 @@ def job_units():
 if __name__ == "__main__":
     jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
                 prep=job_prep, units=job_units, seed16k=job_seed16k, synth48k_p80=job_synth48k_p80,
-                prep48k60=job_prep48k60, synth16k_60s=job_synth16k_60s, synth48k_2s=job_synth48k_2s)
+                prep48k60=job_prep48k60, synth16k_60s=job_synth16k_60s, synth48k_2s=job_synth48k_2s,
+                male16k_2s=job_male16k_2s)
     for j in sys.argv[1:]:
         jobs[j]()
