@@ -240,6 +240,7 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   if (!tile_path)   // the frame queue of the large-frame kernel when it takes every frame
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
   B.debug = ctx->dbg_keep ? (unsigned long long*)(counters + 16) : nullptr;
+  B.debug_diag = ctx->dbg_keep >= 2;
   B.scratch = (double*)ctx->scratch;
   int min_nb = 0;
   rc = launch_ls_prepass(ctx, B, track_t0);

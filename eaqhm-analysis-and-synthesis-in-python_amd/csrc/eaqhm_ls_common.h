@@ -39,6 +39,7 @@ struct LsArgs {
   // Classes 0-5 are the register budgets of eaqhm_ls_tile_kernel, class LS_BIG_CLASS is left to eaqhm_ls_mfma_kernel.
   int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
+  int debug_diag;             // also time diag_D and the gaps between two of them (slots 9, 11, 13, 14; costs ~8 %)
   int* fault;                 // device counters (eaqhm_ctx::faults): [0] singular systems, [1] stalled diagonal pipelines
 };
 

@@ -386,9 +386,10 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
         if (mine) {
           unsigned long long td0 = 0;
           unsigned long long* tlast = (unsigned long long*)(dflag + 2);   // (diagnostics: end of the previous diag_D)
-          if (dbg) td0 = __builtin_amdgcn_s_memtime();
+          const bool tdiag = dbg && uni(A.debug_diag);
+          if (tdiag) td0 = __builtin_amdgcn_s_memtime();
           diag_D(Rt, It, post, nullptr, dflag, 16 * jb, dumpD, LdR, LdI, jb == nt - 1);
-          if (dbg && lane == 0) {   // slots 9 / 11 / 13 / 14: cycles inside diag_D, from one diag_D to the next, counts
+          if (tdiag && lane == 0) {   // slots 9 / 11 / 13 / 14: cycles inside diag_D, from one diag_D to the next, counts
             const unsigned long long td1 = __builtin_amdgcn_s_memtime();
             atomicAdd(dbg + 9, td1 - td0);
             if (jb > 0) { atomicAdd(dbg + 11, td0 - *tlast); atomicAdd(dbg + 14, 1ull); }

@@ -58,7 +58,7 @@ const char* eaqhm_last_error(eaqhm_ctx* ctx);
  *                         3 = Gramian and tile Cholesky on chip for frames of <= 13 tile rows (Kc <= 103), the
  *                             large-frame kernel for the rest (default) */
 #define EAQHM_OPT_LS_VARIANT 1
-#define EAQHM_OPT_DEBUG_KEEP 2   /* 1: accumulate the in-kernel phase stamps across launches */
+#define EAQHM_OPT_DEBUG_KEEP 2   /* 1: accumulate the in-kernel phase stamps across launches; 2: also time diag_D */
 int eaqhm_set_option(eaqhm_ctx* ctx, int32_t key, int32_t value);
 /* diagnostics: shader-clock cycles per phase of the LS tile kernel summed over frames (thread 0 of each
  * workgroup): {setup, basis build, contraction, factorisation total..., see csrc/eaqhm_ls_tile.hip STAMP} */

@@ -4,11 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from eaqhm_amd.engine import DeviceAnalysis, FramePlan
-wl = sys.argv[1] if len(sys.argv) > 1 else "synth16k_60s"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+wl = args[0] if args else "synth16k_60s"
 fs, s, grid, frames, fstep = bench.load_workload(wl)
 plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
 eng = DeviceAnalysis(s, s, plan, 160, 5)
-eng.ctx.set_option(2, 1)
+eng.ctx.set_option(2, 2 if "--diag" in sys.argv else 1)     # --diag: also time diag_D and the gaps (slows the kernel ~8 %)
 eng.run()
 d = eng.ctx.debug_read()
 names = ["setup + slot preparation", "build: barrier wait", "contraction (a>=1) / closed-form fill (a=0)", "(end of factorisation)",
