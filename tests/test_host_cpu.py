@@ -281,6 +281,21 @@ def test_time_block_streaming_matches_resident_run_host_logic():
         DeviceAnalysis(s, s, plan, 100, 2, ctx=OracleBackend(), track_budget_bytes=1000)
 
 
+def test_bench_self_launch_returns_a_failed_rank_promptly():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself; when a rank fails (here: no GPU in this
+    container) the parent must return its exit code at once instead of waiting for the others."""
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ranks would run")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert b"needs an MI355X" in r.stderr and r.stdout.strip() == b""
+
+
 def _pitch_profile(t, profile):
     f0 = 220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t)
     if profile == "step":      # a pitch track that drops to 0.7 of the true pitch half way: the second half's frames
