@@ -160,3 +160,36 @@ def test_config5_60s_48khz_time_block_streaming():
         assert np.array_equal(res["fin"][k], stm["fin"][k]), k
     d = s - res["fin"]["s_recon"]
     assert abs(20 * np.log10(np.std(s) / np.std(d)) - max(res["srer"])) < 1e-9
+
+
+def test_ten_minutes_16khz_streaming_equals_resident():
+    """A file ten times the headline workload (9.6 M samples, 639,936 LS frames per adaptation; the one-minute signal and
+    its pitch grid tiled): 64 MiB of dense tracks instead of 9.1 GB — ~150 time blocks — must reproduce the resident run's
+    SRER list, records and reconstruction bit for bit over adaptations 0-2."""
+    import torch
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.synth import synth_speech_int16
+    fs, minutes = 16000, 10
+    s1 = synth_speech_int16(60.0, fs) / 32768.0
+    g1 = load_golden("prep_fixtures.npz")["synth16k_60s_f0s_5ms"]
+    s = np.tile(s1, minutes)
+    n5 = len(np.arange(0, len(s) - 1, round(fs * 5 / 1000)))
+    f0 = np.resize(g1[:, 1], n5)                       # (12,000 five-ms frames per minute: the grid repeats with the signal)
+    grid = np.column_stack((np.arange(n5) * 0.005, f0))
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    assert plan.n_frames == 639936
+    got = {}
+    for name, budget in (("streaming", 64 << 20), ("resident", None)):
+        torch.cuda.empty_cache()
+        eng = DeviceAnalysis(s, s, plan, 160, 2, track_budget_bytes=budget)
+        eng.run()
+        got[name] = (len(eng.blocks), eng.track_bytes(), [float(v) for v in eng.SRER], eng.records[1].cpu().numpy(),
+                     eng.s_hat[1].cpu().numpy())
+        del eng
+    st, rs = got["streaming"], got["resident"]
+    assert st[0] > 100 and st[1] <= (64 << 20) and rs[0] == 1 and rs[1] > 9e9
+    assert st[2] == rs[2] and len(st[2]) == 3 and st[2][1] > st[2][0] > 50
+    assert np.array_equal(st[3], rs[3]) and np.array_equal(st[4], rs[4])
