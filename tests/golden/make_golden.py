@@ -27,6 +27,7 @@ Usage:
     python tests/golden/make_golden.py synth16k_60s    # the headline workload at full size: 60 s @16 kHz, maxAdpt=5 (~1 h, ~5 GB)
     python tests/golden/make_golden.py synth48k_2s     # 2 s synthetic @48 kHz full band, maxAdpt=1 (~10 min)
     python tests/golden/make_golden.py male16k_2s      # 2 s of a low voice @16 kHz (`male`), maxAdpt=2: large frames
+    python tests/golden/make_golden.py options16k      # 1.5 s @16 kHz with every host-side option off its default
 """
 import os
 import sys
@@ -437,6 +438,26 @@ def job_male16k_2s():
     save("male16k_2s_adpt2.npz", o)
 
 
+OPTIONS16K = dict(gender=(150, 320), step=12, maxAdpt=3, pitchPeriods=4, analysisWindow=40, fullWaveform=False, fc=60,
+                  partials=25)
+
+
+def job_options16k():
+    """Every host-side option of the signature off its default at once, through the reference: tuple gender
+    (functions.py:95-97), step, pitchPeriods, analysisWindow, fullWaveform=False (:127-138), fc > 0 (:90-91),
+    partials > 0 (:117-118).  The returned structs are kept whole (amplitudes / frequencies / phases of every cell)."""
+    fs = 16000
+    x = synth_speech_int16(1.5, fs)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(dense_adpts=(), rec_adpts=(1,))
+    kw = dict(OPTIONS16K)
+    gender = kw.pop("gender")
+    o = run_reference(wav, gender, cap, **kw)
+    o["wav_int16"] = x
+    os.unlink(wav)
+    save("options16k_1p5s.npz", o)
+
+
 def job_prep48k60():
     xs = synth_speech_int16(60.0, 48000)
     r = prep_only(xs, 48000, "female")
@@ -526,6 +547,6 @@ if __name__ == "__main__":
     jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
                 prep=job_prep, units=job_units, seed16k=job_seed16k, synth48k_p80=job_synth48k_p80,
                 prep48k60=job_prep48k60, synth16k_60s=job_synth16k_60s, synth48k_2s=job_synth48k_2s,
-                male16k_2s=job_male16k_2s)
+                male16k_2s=job_male16k_2s, options16k=job_options16k)
     for j in sys.argv[1:]:
         jobs[j]()

@@ -405,6 +405,39 @@ def test_option_paths_against_oracle(amd, tmp_path):
     assert np.array_equal([d.isVoiced for d in det], ref["isVoiced"])
 
 
+def test_option_paths_against_the_reference(amd, tmp_path):
+    """Every host-side option of the signature off its default at once — tuple gender (functions.py:95-97), step,
+    pitchPeriods, analysisWindow, fullWaveform=False (:127-138), fc > 0 (:90-91), partials > 0 (:117-118) — against the
+    reference's own run with those options (tests/golden/make_golden.py options16k): SRER of all four adaptations, the
+    reconstruction, the flags and every cell of the returned structs; once with the reference's pitch track and once
+    with this package's own SWIPE' on the pre-filtered signal."""
+    from scipy.io import wavfile
+    g = load_golden("options16k_1p5s.npz")
+    path = str(tmp_path / "opt_ref.wav")
+    wavfile.write(path, 16000, g["wav_int16"])
+    kw = dict(step=12, maxAdpt=3, pitchPeriods=4, analysisWindow=40, fullWaveform=False, fc=60, partials=25,
+              printPrompts=False)
+    for track in (g["swipe_track"], None):
+        s_recon, SRER, det, _ = amd.eaQHMAnalysisAndSynthesis(path, (150, 320), pitch_track=track, **kw)
+        assert len(SRER) == len(g["SRER"]) == 4 and np.abs(np.array(SRER) - g["SRER"]).max() < TOL_SRER_DB
+        assert np.abs(s_recon - g["s_recon"]).max() <= 1e-9
+        assert np.array_equal([d.ti for d in det], g["det_ti"])
+        assert np.array_equal([d.isSpeech for d in det], g["det_isSpeech"])
+        assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
+        v = g["det_isVoiced"]
+        assert np.abs(np.array([float(d.a0) for d in det if d.isVoiced]) - g["det_a0"][v]).max() <= TOL_AM_REL
+        assert np.array_equal([len(d.amplitudes) if d.isVoiced else 0 for d in det], g["det_len"])
+        cells = g["det_cells"]
+        got = np.array([[float(det[i].amplitudes[k][0]) if isinstance(det[i].amplitudes[k], np.ndarray) else 0.0,
+                         float(det[i].frange[k][0]) if isinstance(det[i].frange[k], np.ndarray) else 0.0,
+                         float(det[i].pk[k][0]) if isinstance(det[i].pk[k], np.ndarray) else 0.0] for i, k in cells])
+        ok = got[:, 0] != 0
+        assert ok.mean() >= 0.999
+        assert np.abs(got[ok, 0] - g["det_am"][ok]).max() <= TOL_AM_REL * g["det_am"].max()
+        assert np.abs(got[ok, 1] - g["det_fm"][ok]).max() <= TOL_FM_HZ
+        assert np.abs(wrap(got[ok, 2] - g["det_pk"][ok])).max() <= TOL_PH_RAD
+
+
 def test_sa19_large_frame_kernel_on_every_frame(amd, sa19_golden):
     """The large-frame LS kernel (MFMA Gramian in passes, tile Cholesky through memory) forced onto every SA19
     frame (EAQHM_OPT_LS_VARIANT = 2): three adaptations (modes 0 and 1) against the reference's SRER."""

@@ -75,6 +75,19 @@ def test_voiced_only_run(sa19_signal):
     assert np.abs(r["s_recon"] - g["s_recon"]).max() < 1e-11
 
 
+def test_every_option_off_its_default():
+    """Tuple gender, step, pitchPeriods, analysisWindow, fullWaveform=False, fc > 0 and partials > 0 at once
+    (tests/golden/make_golden.py options16k): the oracle, fed the pre-processing outputs of the reference's run, against
+    the SRER of its four adaptations, its reconstruction and its flags."""
+    g = load_golden("options16k_1p5s.npz")
+    s = O.ellip_filter(g["wav_int16"] / 32768.0, 16000, 60)                              # functions.py:90-91
+    r = O.analyse(s, 16000, g["f0s_5ms"], g["vuv_ti"], g["vuv_isSpeech"], g["vuv_isVoiced"], int(g["frame_step"]),
+                  f0min=150, maxAdpt=3, step=12, pitchPeriods=4, analysisWindow=40, fullWaveform=False, partials=25)
+    assert len(r["SRER"]) == 4 and np.abs(np.array(r["SRER"]) - g["SRER"]).max() < 1e-9
+    assert np.array_equal(r["isSpeech"], g["det_isSpeech"]) and np.array_equal(r["isVoiced"], g["det_isVoiced"])
+    assert np.abs(r["s_recon"] - g["s_recon"]).max() < 1e-11
+
+
 def test_synth16k_run():
     g = load_golden("synth16k_2s_adpt3.npz")
     s = g["wav_int16"] / 32768.0
