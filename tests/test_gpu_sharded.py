@@ -83,7 +83,7 @@ def test_two_ranks_one_gpu_matches_reference(tmp_path, sa19_golden):
 
 def test_two_ranks_seeding_across_the_rank_boundary(tmp_path):
     """The silent span (instants 534-719) straddles the boundary between the two ranks' instant ranges: seeded rows of
-    rank 0 are visible inside rank 1's first windows only through the halo frames' flags (engine.py n_ext)."""
+    rank 0 are visible inside rank 1's first windows only through the halo frames' flags (engine.py: the frame tables start at ext0, before the rank's first frame)."""
     import torch.multiprocessing as mp
     from test_gpu_parity import check_seeding_result
     g = load_golden("seed16k_1p2s_adpt6.npz")
