@@ -358,7 +358,7 @@ def main():
     frac_ge1 = (f_ge1 / t_ge1 / 1e12 / PEAK_FP64_TFLOPS) if t_ge1 > 0 else None
     ms0 = [t for a, t in zip(ls_a, ls_ms) if a == 0]
     # HBM traffic of that kernel: not measurable from inside this process; taken from the committed rocprofv3 PMC
-    # passes of this same command and workload (profiles/r02_<workload>/pmc_hbm_traffic.json), N = 1 only
+    # passes of this same command and workload (profiles/r03_<workload>/pmc_hbm_traffic.json), N = 1 only
     # (the PMC passes of tools/profile_round.sh; used only if they were taken with exactly these kernel sources)
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r03_%s" % args.workload, "pmc_hbm_traffic.json")
