@@ -122,9 +122,11 @@ def test_pack_results_fast_and_equal_to_the_cell_loop():
     am[5000] = 0                                  # a voiced instant without any accepted harmonic
     fin = dict(am=am, fm=am * 1000, pk=am - 0.5, a0=rng.standard_normal(T))
     plan = SimpleNamespace(ti=np.arange(1, 15 * T, 15), No_ti=T, analysed=analysed, in_bounds=in_bounds)
-    t0 = time.time()
-    det = pack_results(plan, fin)
-    took = time.time() - t0
+    took = float("inf")
+    for _ in range(2):                      # best of two: the container's load varies
+        t0 = time.time()
+        det = pack_results(plan, fin)
+        took = min(took, time.time() - t0)
     assert len(det) == T
 
     def cell_loop(rows):          # round 2's packing: one numpy.array([v]) per cell (misc.py:89-93 taken literally)
