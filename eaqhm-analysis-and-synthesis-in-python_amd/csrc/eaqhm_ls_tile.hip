@@ -547,13 +547,14 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArg
 // look-ups per slot whether its window needs bridging, instead of scanning n windows of N samples.
 // fm / zloc: biased by the first resident sample t_lo (LsArgs), rows of Lt samples; samples outside [t_lo, t_lo + Lt) are
 // not resident (no frame window of this launch reaches them) and count as nonzero.
+// Grid: x = the 1024-sample chunks that overlap the resident window (first one: ch0), y = slots.
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_zero_prefix_kernel(const double* __restrict__ fm, long long Lt,
-                                                                              long long t_lo, int zchunks,
+                                                                              long long t_lo, int ch0, int zchunks,
                                                                               const unsigned char* __restrict__ zflag,
                                                                               unsigned short* __restrict__ zloc,
                                                                               int* __restrict__ ztot) {
   __shared__ int wsum[4];
-  const int k = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y, ch = ch0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (!zflag[ch]) return;   // no frame of this launch (this rank) looks here
   const long long base = (long long)ch << 10;
   int run = 0;
@@ -627,8 +628,10 @@ int launch_ls_prepass(eaqhm_ctx* ctx, LsArgs A, long long track_t0) {
   hipLaunchKernelGGL(eaqhm_ls_classify_kernel, dim3((A.n_frames + 255) / 256), dim3(256), 0, ctx->stream, A);
   HIP_TRY(ctx, hipGetLastError());
   if (A.mode == 1) {
-    hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(A.zchunks, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.Lt,
-                       track_t0, A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
+    // only the chunks the resident track window overlaps (a time block of a long file is a small part of the file)
+    const int ch0 = (int)(track_t0 >> 10), ch1 = (int)((track_t0 + A.Lt - 1) >> 10);
+    hipLaunchKernelGGL(eaqhm_ls_zero_prefix_kernel, dim3(ch1 - ch0 + 1, A.Kmax), dim3(256), 0, ctx->stream, A.fm_cur, A.Lt,
+                       track_t0, ch0, A.zchunks, A.zflag, (unsigned short*)A.zloc, (int*)A.ztot);
     HIP_TRY(ctx, hipGetLastError());
   }
   return EAQHM_OK;
