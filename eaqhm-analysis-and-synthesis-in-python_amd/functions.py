@@ -92,7 +92,7 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
                               fullWaveform: bool = True, fc: int = 0, partials: int = 0,
                               printPrompts: bool = True, loadingScreen: bool = True, *,
                               pitch_track=None, device_index: int = 0, track_budget_bytes=None,
-                              _return_engine: bool = False):
+                              det_format: str = "structs", _return_engine: bool = False):
     """Adaptive quasi-harmonic analysis/resynthesis of a mono 16-bit .wav on an MI355X.
 
     Parameters and returns: exactly those of the reference (functions.py:38-82).  `loadingScreen` is
@@ -106,7 +106,14 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
                     None keeps them resident for the whole file (the reference keeps seven (L, Kmax) arrays,
                     functions.py:159-171); with a budget the frames are worked off in time blocks whose tracks are
                     regenerated from the frame-centre records — same results, bit for bit
+      det_format    "structs" (default): DetComponents is the reference's list of Deterministic objects
+                    (functions.py:404-411).  "arrays": a dict of NumPy arrays instead — ti, isSpeech, isVoiced (per
+                    instant), a0 (No_ti,), amplitudes / frange / pk (No_ti, Kmax; zero where a slot is inactive) — for
+                    callers that do not want ~100 Python objects per analysis instant (building them takes four times
+                    as long as the whole analysis of a minute of speech)
     """
+    if det_format not in ("structs", "arrays"):
+        raise ValueError("det_format must be 'structs' or 'arrays'")
     start = time()
     plan, eng = _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc,
                          partials, pitch_track, device_index, track_budget_bytes)
@@ -122,7 +129,7 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
 
     eng.run(on_adaptation=report)
     fin = eng.final_arrays()
-    det = pack_results(plan, fin)
+    det = pack_results(plan, fin) if det_format == "structs" else pack_arrays(plan, fin)
     end_time = time() - start
     if printPrompts:                                                             # functions.py:414-416
         print('Signal adapted to {} dB SRER'.format(round(max(eng.SRER), 6)))
@@ -182,6 +189,19 @@ def pack_results(plan, fin):
         d.frange = freqs[j]
         d.pk = phases[j]
     return det
+
+
+def pack_arrays(plan, fin):
+    """The content of functions.py:404-411 as plain arrays (det_format="arrays")."""
+    voiced = np.asarray(plan.analysed, dtype=bool)
+    out = dict(ti=(plan.ti - 1).astype(np.int64), isSpeech=np.asarray(plan.in_bounds, dtype=bool), isVoiced=voiced,
+               a0=np.where(voiced, fin["a0"], 0.0))
+    for name, key in (("amplitudes", "am"), ("frange", "fm"), ("pk", "pk")):
+        arr = np.array(fin[key], dtype=np.float64)
+        arr[fin["am"] == 0] = 0.0
+        arr[~voiced] = 0.0
+        out[name] = arr
+    return out
 
 
 def _column(x):

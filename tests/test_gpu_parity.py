@@ -220,6 +220,29 @@ def test_entry_point_signature_and_synth16k(amd):
     assert np.array_equal([d.isVoiced for d in det], g["det_isVoiced"])
 
 
+def test_det_format_arrays_equals_structs(amd, sa19_golden):
+    """Keyword-only extension det_format="arrays": the same numbers as the Deterministic list, as plain arrays."""
+    wav = os.path.join(GOLDEN, "SA19.WAV")
+    kw = dict(maxAdpt=1, printPrompts=False, pitch_track=sa19_golden["swipe_track"])
+    _, srer_s, det, _ = amd.eaQHMAnalysisAndSynthesis(wav, "female", **kw)
+    _, srer_a, arr, _ = amd.eaQHMAnalysisAndSynthesis(wav, "female", det_format="arrays", **kw)
+    assert srer_s == srer_a and set(arr) == {"ti", "isSpeech", "isVoiced", "a0", "amplitudes", "frange", "pk"}
+    assert np.array_equal(arr["ti"], [d.ti for d in det]) and np.array_equal(arr["isVoiced"], [d.isVoiced for d in det])
+    assert np.array_equal(arr["isSpeech"], [d.isSpeech for d in det])
+    for i in (0, 40, 41, 1000, 2500, 4200, 4232):
+        d = det[i]
+        if not d.isVoiced:
+            assert not arr["amplitudes"][i].any() and arr["a0"][i] == 0
+            continue
+        assert arr["a0"][i] == d.a0
+        for name in ("amplitudes", "frange", "pk"):
+            row, obj = arr[name][i], getattr(d, name)
+            assert not row[len(obj):].any()
+            assert all((row[k] == obj[k][0]) if isinstance(obj[k], np.ndarray) else (row[k] == 0) for k in range(len(obj)))
+    with pytest.raises(ValueError):
+        amd.eaQHMAnalysisAndSynthesis(wav, "female", det_format="json")
+
+
 def test_voiced_only_option(amd):
     """fullWaveform=False (functions.py:127-138) against the reference's run."""
     g = load_golden("sa19_female_voicedonly_adpt1.npz")
