@@ -28,6 +28,7 @@ Usage:
     python tests/golden/make_golden.py synth48k_2s     # 2 s synthetic @48 kHz full band, maxAdpt=1 (~10 min)
     python tests/golden/make_golden.py male16k_2s      # 2 s of a low voice @16 kHz (`male`), maxAdpt=2: large frames
     python tests/golden/make_golden.py options16k      # 1.5 s @16 kHz with every host-side option off its default
+    python tests/golden/make_golden.py child16k_2s     # 2 s of a high voice @16 kHz (`child`): systems of 4-7 tile rows
 """
 import os
 import sys
@@ -458,6 +459,22 @@ def job_options16k():
     save("options16k_1p5s.npz", o)
 
 
+def job_child16k_2s():
+    """A high voice: the generator's 4 s @8 kHz read as 2 s @16 kHz (every frequency doubles: f0 340-540 Hz, 14 partials),
+    gender `child` (300-600 Hz).  Frames of 29-53 basis columns: systems of 4-7 tile rows, the small end of the on-chip
+    tile kernel's first size class."""
+    fs = 16000
+    x = synth_speech_int16(4.0, 8000)
+    wav = write_wav_int16(x, fs)
+    cap = Capture(ls_frames_iqhm=(300,), ls_frames_eaqhm=(300,), dense_adpts=(), rec_adpts=(1,), ls_outputs_only=True)
+    o = run_reference(wav, "child", cap, maxAdpt=4)
+    o["wav_int16"] = x
+    for k in ("det_cells", "det_am", "det_fm", "det_pk"):
+        o.pop(k, None)
+    os.unlink(wav)
+    save("child16k_2s_adpt4.npz", o)
+
+
 def job_prep48k60():
     xs = synth_speech_int16(60.0, 48000)
     r = prep_only(xs, 48000, "female")
@@ -547,6 +564,7 @@ if __name__ == "__main__":
     jobs = dict(sa19=job_sa19, sa19_vuv=job_sa19_vuv, synth16k=job_synth16k, synth48k=job_synth48k,
                 prep=job_prep, units=job_units, seed16k=job_seed16k, synth48k_p80=job_synth48k_p80,
                 prep48k60=job_prep48k60, synth16k_60s=job_synth16k_60s, synth48k_2s=job_synth48k_2s,
-                male16k_2s=job_male16k_2s, options16k=job_options16k)
+                male16k_2s=job_male16k_2s, options16k=job_options16k,
+                child16k_2s=job_child16k_2s)
     for j in sys.argv[1:]:
         jobs[j]()

@@ -742,6 +742,50 @@ def test_low_voice_16khz_large_frames_against_reference(amd):
     assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9
 
 
+def test_high_voice_16khz_small_systems_against_reference(amd):
+    """A high (`child`) voice at 16 kHz through the reference itself (tests/golden/make_golden.py child16k_2s): 14 partials,
+    the smallest systems the on-chip tile kernel sees (few tile rows), five adaptations that all improve: the SRER list,
+    raw LS solutions of a captured frame of adaptations 0 and 1, the frame-centre records of adaptation 1, the
+    reconstruction."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    g = load_golden("child16k_2s_adpt4.npz")
+    fs = 16000
+    s = g["wav_int16"] / 32768.0
+    grid = prologue.resample_track(g["swipe_track"], np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "child")
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    sh = g["ls_shapes_iqhm"]
+    assert np.array_equal(2 * plan.frame_wl + 1, sh[:, 0]) and np.array_equal(2 * plan.frame_K + 1, sh[:, 1])
+    eng = DeviceAnalysis(s, s, plan, 300, 4, keep_raw=True)
+    seen = {}
+
+    def hook(a, e):
+        if a <= 1:
+            key = "iqhm300_" if a == 0 else "eaqhm300_"
+            assert int(g[key + "tith"]) - 1 == int(plan.frame_c[300])
+            amp, slo = _raw_of(e, 300)
+            Kc = len(g[key + "amp"])
+            assert relerr(amp[:Kc], g[key + "amp"]) < 1e-9 and relerr(slo[:Kc], g[key + "slope"]) < 1e-8, a
+        seen[a] = e.records[0][:plan.No_ti].cpu().numpy().copy()
+
+    eng.run(on_adaptation=hook)
+    record_measurement("child16k_2s", srer_hip=[float(v) for v in eng.SRER], srer_reference=[float(v) for v in g["SRER"]],
+                       Kc_min=int(sh[:, 1].min()), Kc_max=int(sh[:, 1].max()))
+    assert len(eng.SRER) == len(g["SRER"]) == 5 and np.abs(np.array(eng.SRER) - g["SRER"]).max() < TOL_SRER_DB
+    ref = unpack_records(g, 1)
+    K = plan.Kmax
+    am, fm, ph = seen[1][:, :K], seen[1][:, K:2 * K], seen[1][:, 2 * K:3 * K]
+    assert np.mean((am != 0) == ref["mask"]) >= 0.999
+    both = (am != 0) & ref["mask"]
+    assert np.abs(am[both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(fm[both] - ref["fm"][both]).max() <= TOL_FM_HZ
+    strong = both & (ref["am"] > 1e-6 * ref["am"].max())
+    assert np.abs(wrap(ph[strong] - ref["ph"][strong])).max() <= TOL_PH_RAD
+    assert np.abs(eng.final_arrays()["s_recon"] - g["s_recon"]).max() <= 1e-9
+
+
 # ----------------------------------------------------------------------------- empty-row seeding (Q7 / Q8)
 def check_seeding_result(g, srer, seen, fin, raw510=None):
     """Shared by the single-GPU and the two-rank test: everything the reference's run on the signal with the span of
