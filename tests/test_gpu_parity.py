@@ -347,6 +347,56 @@ def test_against_oracle_seeded_signal(amd, params):
     assert np.abs(wrap(fin["pk"][both] - ref["pk"][both])).max() <= loose * TOL_PH_RAD
 
 
+@pytest.mark.parametrize("fs,dur,gender", [(8000, 0.8, "female"), (22050, 0.45, "female"), (44100, 0.3, "other"),
+                                           (11025, 0.7, "male")])
+def test_other_sampling_rates_against_oracle(amd, fs, dur, gender):
+    """Sampling rates the fixtures do not have (telephone band to CD rate; the reference takes whatever the wav file says,
+    functions.py:86): frame geometry, Fmax = fs/2 - 200, Kmax and the window lengths all change with fs, and with them
+    which LS kernel a frame takes.  HIP path against the oracle on the same seeded input and the same analytic pitch track,
+    adaptations 0-1."""
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.synth import synth_speech_int16
+    s = synth_speech_int16(dur, fs) / 32768.0
+    t = np.arange(0, len(s) / fs + 0.002, 0.001)      # (one ms more than SWIPE' gives: at 44.1 kHz the 5 ms grid of
+    scale = 0.5 if gender == "male" else 1.0          #  functions.py:113 ends after the last whole millisecond)
+    f0 = scale * (220.0 + 40.0 * np.sin(2 * np.pi * 0.31 * t) + 10.0 * np.sin(2 * np.pi * 1.7 * t))
+    f0min = prologue.pitch_limits(gender)[0]
+    grid = prologue.resample_track(np.column_stack([t, f0, np.ones_like(t)]),
+                                   np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, gender)
+    ti5 = np.array([f.ti for f in frames])
+    sp = np.array([float(f.isSpeech) for f in frames])
+    vo = np.array([float(f.isVoiced) for f in frames])
+    seen_ref = {}
+    ref = O.analyse(s, fs, grid, ti5, sp, vo, fstep, f0min=f0min, maxAdpt=1,
+                    on_adaptation=lambda a, rec, st: seen_ref.update({a: {k: np.array(v) for k, v in rec.items()}}))
+    prologue.apply_full_waveform(frames, len(s), 32 * 15)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    assert plan.n_frames == ref["n_ls_frames"] // len(ref["SRER"]) and plan.n_frames > 100
+    seen = {}
+    eng = DeviceAnalysis(s, s, plan, f0min, 1)
+    eng.run(on_adaptation=lambda a, e: seen.update({a: e.records[0][:plan.No_ti].cpu().numpy().copy()}))
+    record_measurement("fs_%d_%s" % (fs, gender), srer_hip=[float(v) for v in eng.SRER],
+                       srer_oracle=[float(v) for v in ref["SRER"]], Kmax=int(plan.Kmax),
+                       Kc_max=int(2 * plan.frame_K.max() + 1), N_max=int(2 * plan.frame_wl.max() + 1))
+    assert len(eng.SRER) == len(ref["SRER"]) == 2
+    assert abs(eng.SRER[0] - ref["SRER"][0]) < TOL_SRER_DB and abs(eng.SRER[1] - ref["SRER"][1]) < TOL_SRER_NYQUIST_DB
+    K = plan.Kmax
+    for a in (0, 1):
+        am, ph = seen[a][:, :K], seen[a][:, 2 * K:3 * K]
+        r = seen_ref[a]
+        m = r["am"] != 0
+        assert np.mean((am != 0) == m) >= 0.999
+        both = m & (am != 0)
+        q = np.abs(am[both] - r["am"][both]) / r["am"].max()
+        assert np.quantile(q, 0.999) <= TOL_AM_REL and q.max() <= 1e-6      # (worst cells: noise-only margins, cf. the low voice)
+        strong = both & (r["am"] > 1e-6 * r["am"].max())
+        assert np.quantile(np.abs(wrap(ph[strong] - r["ph"][strong])), 0.999) <= TOL_PH_RAD
+    assert np.abs(eng.final_arrays()["s_recon"] - ref["s_recon"]).max() <= 1e-8
+
+
 def test_long_windows_against_oracle(amd):
     """A low voice at 32 kHz (f0 86-94 Hz, 'male' limits): windows of 1020-1120 samples — longer than the 1024-sample
     chunks of the zero counts and than the 16 x 64-sample masks the register-resident kernel is laid out for — and
