@@ -47,10 +47,10 @@ extern "C" int eaqhm_sync(eaqhm_ctx* ctx) {
 
 extern "C" const char* eaqhm_last_error(eaqhm_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
-extern "C" int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t h_count[2]) {
+extern "C" int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t h_count[3]) {
   if (!ctx || !h_count) return EAQHM_EINVAL;
-  HIP_TRY(ctx, hipMemcpyAsync(h_count, ctx->faults, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->faults, 0, 2 * sizeof(int32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_count, ctx->faults, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->faults, 0, 3 * sizeof(int32_t), ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return EAQHM_OK;
 }

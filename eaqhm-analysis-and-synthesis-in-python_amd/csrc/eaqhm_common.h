@@ -21,7 +21,8 @@ struct eaqhm_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int* faults = nullptr;   // device counters: [0] LS systems whose Cholesky broke down (singular normal matrix),
-                           // [1] diagonal pipelines whose hand-shake timed out (eaqhm_ls_chol.h: spin_until)
+                           // [1] diagonal pipelines whose hand-shake timed out (eaqhm_ls_chol.h: spin_until),
+                           // [2] frames dropped because their window was not inside the resident tracks / the signal
   char err[512] = {0};
 
   int fail(int code, const char* msg) {

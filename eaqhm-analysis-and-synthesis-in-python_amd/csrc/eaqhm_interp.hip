@@ -427,7 +427,7 @@ extern "C" __global__ void __launch_bounds__(256) eaqhm_eval_kernel(EvalArgs A, 
 // Adds the blocks' limbs (integers: any order gives the same result), carries them into two 128-bit totals and leaves
 //   sums_out[0..3]  sum d, sum d^2, n, SRER in dB — doubles, a convenience for C callers; the Python host derives the
 //                   SRER itself from the limbs (one formula for every world size and block count)
-//   sums_out[4..5]  LS faults / stalled diagonal pipelines since the last read (both counters are cleared)
+//   sums_out[4..6]  LS breakdowns / stalled diagonal pipelines / dropped frames since the last read (counters are cleared)
 //   sums_out[8..15] the limbs as int64 bit patterns: what ranks and time blocks add up
 extern "C" __global__ void __launch_bounds__(1024) eaqhm_srer_kernel(const long long* partials, long long nblocks, double n,
                                                                     double std_det, double* sums_out, int* faults) {
@@ -458,7 +458,8 @@ extern "C" __global__ void __launch_bounds__(1024) eaqhm_srer_kernel(const long 
     sums_out[3] = e[6] ? __builtin_nan("") : 20.0 * log10(std_det / sqrt(var));
     sums_out[4] = (double)faults[0];   // LS systems whose factorisation broke down in this adaptation (eaqhm_ls_faults)
     sums_out[5] = (double)faults[1];   // diagonal pipelines that timed out (a bug of the library if ever nonzero)
-    faults[0] = 0; faults[1] = 0;
+    sums_out[6] = (double)faults[2];   // frames dropped because their window lay outside the resident track window
+    faults[0] = 0; faults[1] = 0; faults[2] = 0;
   }
 }
 

@@ -210,8 +210,9 @@ extern "C" int eaqhm_ls_batch(eaqhm_ctx* ctx, int32_t mode, const double* s, int
   LsArgs B;
   B.mode = mode; B.s = s; B.L = L; B.fs = fs; B.Kmax = Kmax;
   // tracks (and the zero counts below) biased by the window's first sample: the kernels index with absolute samples.
-  // Every frame window must lie inside [track_t0, track_t0 + track_len): the caller's contract (checked on the host side).
-  B.am_cur = am_cur ? am_cur - track_t0 : nullptr; B.fm_cur = fm_cur ? fm_cur - track_t0 : nullptr; B.Lt = track_len;
+  // Every frame window must lie inside [track_t0, track_t0 + track_len): the caller's contract; a frame that breaks it is
+  // dropped by the classification kernel and counted (fault[2]) instead of reading outside the buffers.
+  B.am_cur = am_cur ? am_cur - track_t0 : nullptr; B.fm_cur = fm_cur ? fm_cur - track_t0 : nullptr; B.Lt = track_len; B.trk_t0 = track_t0;
   B.frame_inst = frame_inst; B.frame_c = frame_c; B.frame_wl = frame_wl; B.frame_f0 = frame_f0; B.frame_K = frame_K;
   B.ncol = ncol; B.cols = cols; B.seeded = seeded; B.any_seed = any_seed; B.n_frames = n_frames; B.a_iter = a_iter;
   B.f0_stale = f0_stale; B.f0min = f0min; B.records = records; B.raw_amp = raw_amp; B.raw_slope = raw_slope;

@@ -24,7 +24,7 @@ struct LsArgs {
   // dense tracks of the previous adaptation: rows of Lt samples that hold samples [t0, t0 + Lt) of the file.  The two
   // pointers (and zloc) are BIASED by -t0 on the host side of the C ABI, so that row k, absolute sample t is at
   // [k * Lt + t] — the kernels index with absolute sample numbers whatever window of the file is resident.
-  const double* am_cur; const double* fm_cur; long long Lt; int Kmax;
+  const double* am_cur; const double* fm_cur; long long Lt; long long trk_t0; int Kmax;
   const int* frame_inst; const int* frame_c; const int* frame_wl; const double* frame_f0; const int* frame_K;
   const int* ncol; const int* cols; const unsigned char* seeded; const int* any_seed;
   int n_frames; int a_iter; double f0_stale; double f0min;
@@ -40,8 +40,18 @@ struct LsArgs {
   int* cls;
   unsigned long long* debug;  // phase stamps (16 x u64)
   int debug_diag;             // also time diag_D and the gaps between two of them (slots 9, 11, 13, 14; costs ~8 %)
-  int* fault;                 // device counters (eaqhm_ctx::faults): [0] singular systems, [1] stalled diagonal pipelines
+  int* fault;                 // device counters (eaqhm_ctx::faults): [0] singular systems, [1] stalled diagonal pipelines,
+                              // [2] frames whose window is not inside the resident track window (dropped, never read)
 };
+
+// The contract of eaqhm_ls_batch checked on the device: the frame's window [c - wl, c + wl] lies inside the signal and —
+// adaptations >= 1, together with the sample before it (the zero counts are differences of running counts) — inside the
+// resident window of the tracks.  A frame that fails is dropped and counted (fault[2]) instead of being read out of bounds.
+__device__ inline bool frame_window_ok(const LsArgs& A, long long c, long long wl) {
+  bool inside = wl > 0 && c - wl >= 0 && c + wl < A.L;
+  if (A.mode == 1) inside = inside && c + wl < A.trk_t0 + A.Lt && (c - wl - 1 >= A.trk_t0 || (A.trk_t0 == 0 && c - wl == 0));
+  return inside;
+}
 
 // wave-uniform values that the compiler cannot prove uniform (loaded through per-lane pointers, passed in vector
 // registers): moved to scalar registers, where the arithmetic on them costs no VGPRs and no VALU cycles

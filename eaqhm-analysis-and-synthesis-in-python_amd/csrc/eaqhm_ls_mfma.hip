@@ -97,6 +97,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     // (adaptation 0: frames of up to MF_A0_M real tile rows were solved on chip by eaqhm_ls_a0big_kernel)
     if (A.mode == 0 && a0_onchip && ((2 * uni(A.frame_K[f]) + 2 + 15) >> 4) <= MF_A0_M) continue;
     const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
+    if (min_nb == 0 && !frame_window_ok(A, c, wl)) continue;   // (counted by the classification kernel; class lists never hold such a frame)
     const int N = 2 * wl + 1, mid = wl;
     const int n = uni((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
     const int Kc = 2 * n + 1, C1 = Kc + 1;
@@ -372,6 +373,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_a0big_kernel(L
     __syncthreads();
     if (item >= n_items) break;
     const int f = uni((min_nb > 0) ? A.cls[16 + (size_t)LS_BIG_CLASS * A.n_frames + item] : item);
+    if (min_nb == 0 && !frame_window_ok(A, uni(A.frame_c[f]), uni(A.frame_wl[f]))) continue;   // (see eaqhm_ls_mfma_kernel)
     const int m0 = (2 * uni(A.frame_K[f]) + 2 + 15) >> 4;
     if (m0 <= 13) a0_frame<12, MF_A0_M, 1>(A, lds, f, TB, MF_A0_NCH, WP, NP);
     else if (m0 <= 16) a0_frame<17, MF_A0_M, 1>(A, lds, f, TB, MF_A0_NCH, WP, NP);

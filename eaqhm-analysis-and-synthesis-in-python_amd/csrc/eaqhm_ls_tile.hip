@@ -527,8 +527,11 @@ __device__ inline int frame_class(int n) {
 }
 extern "C" __global__ void __launch_bounds__(256) eaqhm_ls_classify_kernel(LsArgs A) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-  const int cl = (f < A.n_frames) ? frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]) : -1;
-  if (A.mode == 1 && f < A.n_frames) {   // chunks of the zero counts this frame's window (and the sample before it) touches
+  int cl = (f < A.n_frames) ? frame_class((A.mode == 0) ? A.frame_K[f] : A.ncol[f]) : -1;
+  if (f < A.n_frames) {   // the frame's window [c - wl, c + wl] inside the signal and (mode 1, with the sample before it) inside the resident tracks
+    if (!frame_window_ok(A, A.frame_c[f], A.frame_wl[f])) { cl = -1; atomicAdd(A.fault + 2, 1); }   // dropped: its record row is not written
+  }
+  if (A.mode == 1 && cl >= 0) {   // chunks of the zero counts this frame's window (and the sample before it) touches
     const long long c = A.frame_c[f], wl = A.frame_wl[f];
     const long long lo = (c - wl - 1 > 0) ? (c - wl - 1) : 0;
     for (long long ch = lo >> 10; ch <= ((c + wl) >> 10); ++ch) A.zflag[ch] = 1;

@@ -430,11 +430,14 @@ class DeviceAnalysis:
         p, sh = self.plan, self.shard
         words = self.sums.view(self.torch.int64)[8:16].clone()
         words[7] = 0
-        counts = self.sums[4:6].to(self.torch.int64)
+        counts = self.sums[4:7].to(self.torch.int64)
         red = self.torch.cat((words, counts))
         sh.all_reduce_sum(red)
         red = red.cpu().numpy()
-        faults, stalled = int(red[8]), int(red[9])
+        faults, stalled, dropped = int(red[8]), int(red[9]), int(red[10])
+        if dropped > 0:
+            raise ValueError("%d frame(s) had their analysis window outside the resident track window (engine defect or a "
+                             "direct caller of eaqhm_ls_batch broke its contract); they were not analysed" % dropped)
         if stalled > 0:
             raise StalledPipeline("%d diagonal-tile pipeline(s) of the LS kernels timed out in this adaptation "
                                   "(library defect, not a singular system)" % stalled)

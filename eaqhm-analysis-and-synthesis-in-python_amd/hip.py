@@ -130,11 +130,11 @@ class Context:
         return [int(v) for v in out]
 
     def ls_faults(self):
-        """(LS systems whose Cholesky broke down, stalled diagonal pipelines) since the last read (waits for the stream,
-        clears the counts)."""
-        n = (_I32 * 2)()
+        """(LS systems whose Cholesky broke down, stalled diagonal pipelines, frames dropped because their window was not
+        resident) since the last read (waits for the stream, clears the counts)."""
+        n = (_I32 * 3)()
         self._ck(self.lib.eaqhm_ls_faults(self.h, n))
-        return int(n[0]), int(n[1])
+        return int(n[0]), int(n[1]), int(n[2])
 
     def sync(self):
         self._ck(self.lib.eaqhm_sync(self.h))

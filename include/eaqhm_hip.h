@@ -70,9 +70,12 @@ int eaqhm_debug_read(eaqhm_ctx* ctx, uint64_t h_out[16]);
  * columns give.  Such frames are counted in a device counter (h_count[0]); ill-conditioned but factorisable systems are
  * solved like the reference solves them.  h_count[1] counts diagonal-tile pipelines whose internal hand-shake timed
  * out — never nonzero unless the library has a bug; the host raises RuntimeError for it, LinAlgError for h_count[0].
- * eaqhm_ls_faults waits for the stream, returns the counts since the last read and clears them; eaqhm_eval_synth also
- * reports (and clears) them in sums_out[4..5], so the adaptation loop needs no extra device->host read. */
-int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t h_count[2]);
+ * h_count[2] counts frames whose analysis window [c-wl-1, c+wl] was not inside the signal / the resident track window
+ * handed to eaqhm_ls_batch: such a frame is dropped (its record row is not written) instead of being read out of bounds;
+ * the host raises ValueError.  eaqhm_ls_faults waits for the stream, returns the counts since the last read and clears
+ * them; eaqhm_eval_synth also reports (and clears) them in sums_out[4..6], so the adaptation loop needs no extra
+ * device->host read. */
+int eaqhm_ls_faults(eaqhm_ctx* ctx, int32_t h_count[3]);
 /* library / device facts: fills {n_cu, lds_bytes, clock_khz, abi_version} */
 int eaqhm_device_info(eaqhm_ctx* ctx, int32_t h_info[4]);
 
@@ -158,8 +161,8 @@ int eaqhm_spline_solve_range(eaqhm_ctx* ctx, const double* records, int32_t No_t
  *   s_hat            double[L]; NULL: tracks only — no synthesis, no ph_knot, no error sums (target, ph_knot,
  *                    partials, sums_out may then be NULL too)
  *   partials         8-byte words, eaqhm_eval_partials_len of them: per-block error sums
- *   sums_out         double[16]: {sum d, sum d^2, n, SRER dB, LS breakdowns and stalled pipelines since the last read
- *                    (see eaqhm_ls_faults), -, -, then eight int64 bit patterns} with d = target - s_hat over
+ *   sums_out         double[16]: {sum d, sum d^2, n, SRER dB, LS breakdowns, stalled pipelines and dropped frames since the
+ *                    last read (see eaqhm_ls_faults), -, then eight int64 bit patterns} with d = target - s_hat over
  *                    [s_lo,s_hi).  The int64 words are the same sums in fixed point — three base-2^32 limbs of
  *                    d*2^60, three of d^2*2^64, the number of samples with |d| >= 2^20 or non-finite, 0 — which add
  *                    up exactly over blocks, ranks and time blocks, so the SRER (functions.py:388, the input of the

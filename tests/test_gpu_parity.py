@@ -972,6 +972,49 @@ def test_ill_conditioned_but_nonsingular_system_is_solved_like_inv(amd):
         amd.eaqhmLS_complexamps(s, am, np.tile(np.array([-200.0, 0.0, 200.0, 200.0]), (N, 1)), w, fs)
 
 
+@pytest.mark.parametrize("variant", [3, 2])
+def test_frames_outside_the_track_window_are_dropped_not_read(amd, sa19_golden, variant):
+    """The contract of eaqhm_ls_batch — every frame window inside the resident track window — checked on the device: a
+    caller that hands a window too small gets the offending frames dropped and counted (eaqhm_ls_faults[2], ValueError from
+    the engine), not an out-of-bounds read.  Both LS kernels."""
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis
+    fs, s = prologue.read_signal(os.path.join(GOLDEN, "SA19.WAV"))
+    s = s[:16000]
+    plan = _plan_for(s, fs, sa19_golden["swipe_track"][:1000])
+    eng = DeviceAnalysis(s, s, plan, 160, 1)
+    eng.ctx.set_option(1, variant)
+    it = eng.adaptations()
+    next(it)
+    next(it)                                    # adaptation 0 read, adaptation 1 enqueued (healthy)
+    eng.torch.cuda.synchronize()
+    assert eng.ctx.ls_faults() == (0, 0, 0)
+    p, c, T = plan, eng.ctx, eng.torch
+    # the tracks are adaptation 1's by now: slot lists of THESE tracks, then the same launch twice — whole file / window
+    ncol, cols = T.zeros_like(eng.ncol), T.zeros_like(eng.cols)
+    seeded, any_seed = T.zeros_like(eng.seeded), T.zeros_like(eng.any_seed)
+    c.frame_prep(eng.fm_cur, p.L, 0, p.L, p.Kmax, eng.frame_c, eng.nf, ncol, cols, seeded, any_seed)
+
+    def launch(am, fm, lo, w):
+        rec = T.zeros_like(eng.records[0])
+        c.ls_batch(1, eng.s, p.L, p.fs, am, fm, lo, w, p.Kmax, eng.frame_inst, eng.frame_c, eng.frame_wl, eng.frame_f0,
+                   eng.frame_K, ncol, cols, seeded, any_seed, eng.nf, p.wl_max, 2, p.f0_stale, eng.f0min, rec)
+        T.cuda.synchronize()
+        return rec[:plan.No_ti].cpu().numpy(), c.ls_faults()
+
+    ref, faults = launch(eng.am_cur, eng.fm_cur, 0, p.L)
+    assert faults == (0, 0, 0) and ref[plan.frame_inst].any(axis=1).all()
+    lo, w = 4000, 6000                          # a resident window [4000, 10000): most frames lie outside it
+    got, faults = launch(eng.am_cur[:, lo:lo + w].contiguous(), eng.fm_cur[:, lo:lo + w].contiguous(), lo, w)
+    fc, fw = plan.frame_c.astype(np.int64), plan.frame_wl.astype(np.int64)
+    inside = (fc - fw - 1 >= lo) & (fc + fw < lo + w)
+    assert inside.sum() > 100 and (~inside).sum() > 100
+    assert faults == (0, 0, int((~inside).sum()))
+    rows = plan.frame_inst
+    assert not got[rows[~inside]].any()                       # dropped frames wrote nothing
+    assert np.array_equal(got[rows[inside]], ref[rows[inside]])  # the others are what they are in the whole-file launch
+
+
 def test_singular_frame_in_batch_raises(amd, sa19_golden):
     """Two slots with identical tracks make two columns of every adaptation >= 1 frame identical: the batched kernel
     counts the collapsed pivots (eaqhm_ls_faults) and the engine raises LinAlgError at the end of that adaptation
