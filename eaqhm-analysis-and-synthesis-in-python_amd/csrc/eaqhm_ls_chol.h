@@ -36,11 +36,12 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
   // the rows of the inverse below the block follow the same elimination on [L | I].  Columns / rows inside a
   // block stay raw until the final scaling, which applies the block's own 2x2 Cholesky factor.
   // (Z must hold the identity and D the tile when the workgroup arrives here: diag_init + the caller's barrier)
+  // (threads beyond 511 of a larger workgroup only join the barriers)
   const int g = tid >> 8, e = tid & 255, i = e >> 4, k = e & 15;  // entry (i, k) of D (g = 0) or Z (g = 1)
   const int eo = i * DG_LD + k;                                    // ... at its padded position
 #pragma clang loop unroll(disable)
   for (int j = 0; j < 14; j += 2) {
-    const bool work = (g == 0) ? (k >= j + 2 && i >= k) : (i >= j + 2 && k <= j + 1);
+    const bool work = (g == 0) ? (k >= j + 2 && i >= k) : ((g == 1) && i >= j + 2 && k <= j + 1);
     if (work) {
       double p = D[2 * (j * DG_LD + j)], r = D[2 * ((j + 1) * DG_LD + j + 1)];
       const double qr = D[2 * ((j + 1) * DG_LD + j)], qi = D[2 * ((j + 1) * DG_LD + j) + 1];
@@ -76,7 +77,7 @@ __device__ inline void diag_coop(double* D, double* Z, double* WtR, double* WtI,
     __syncthreads();
   }
   // final scaling with each pivot block's own Cholesky factor [[l11, 0], [l21, l22]]
-  {
+  if (g < 2) {
     const int pj = ((g == 0) ? k : i) & ~1;    // first column (D) / row (Z) of the entry's pivot block
     double p = D[2 * (pj * DG_LD + pj)], r = D[2 * ((pj + 1) * DG_LD + pj + 1)];
     const double qr = D[2 * ((pj + 1) * DG_LD + pj)], qi = D[2 * ((pj + 1) * DG_LD + pj) + 1];
@@ -530,14 +531,109 @@ __device__ __attribute__((always_inline)) inline void diag_Zr(const double* post
 //  576; 1 x 4: 581; 1 x 5: 578; 3 x 2: 584; 2 x 4 with four products — two accumulators per tile — 593; 2 x 4 with three: 622, spills)
 #define CH_NTMAX 96      // tile rows the work space is sized for (system order 16 * 96)
 __device__ inline size_t tile_off(int P, int Q) { return ((size_t)P * (P + 1) / 2 + Q) * 512; }
-#define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 8 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32 + 16)
+#define CH_LDS_DOUBLES (2 * DG_TILE + 4 * TL_TILE + 16 * 2 * TL_TILE + 2 * 16 * CH_NTMAX + 32 + 16)   // (up to 16 waves)
+
+// One register group of the block update (phase (1) of tile_cholesky_memory): rows Pg (and Pg + 8 when RB = 2), the CH_W
+// columns of the block, T[P][Q0+c] -= sum_{j<Q0} L[P][j] L[Q0+c][j]^H.  The K-loop is branch-free: every one of the
+// RB x CH_W tiles is accumulated (a tile above the diagonal or beyond the last column costs its MFMAs — three tiles
+// per block at most — and is simply not written back), the sums of the three-product form are formed before the MFMAs so
+// that those issue back to back, and two k-steps per trip ping-pong between two operand sets (no register copies).
+template <int RB, int RS>   // RB rows Pg, Pg + RS
+__device__ __attribute__((always_inline)) inline void chol_block_unit(double* __restrict__ T, int Q0, int Wc, int Pg, int lq, int lcol) {
+  d4 cR[RB][CH_W], cI[RB][CH_W], c3[RB][CH_W];
+#pragma unroll
+  for (int m = 0; m < RB; ++m)
+#pragma unroll
+    for (int c = 0; c < CH_W; ++c) {
+      cR[m][c] = (d4){0, 0, 0, 0}; cI[m][c] = (d4){0, 0, 0, 0}; c3[m][c] = (d4){0, 0, 0, 0};
+    }
+  const double* Bp[CH_W];
+  const double* Ap[RB];
+#pragma unroll
+  for (int c = 0; c < CH_W; ++c) Bp[c] = T + tile_off((c < Wc) ? (Q0 + c) : Q0, 0) + lq * 16 + lcol;
+#pragma unroll
+  for (int m = 0; m < RB; ++m) Ap[m] = T + tile_off(Pg + RS * m, 0) + lq * 16 + lcol;
+  // operand sets x (current k-step) and y (next): tile j = it/4 of a row starts 512 j doubles after tile 0, k-step
+  // ks = it%4 is 64 doubles further; the requests of step it+1 are issued before the MFMAs of step it
+  double xbR[CH_W], xbI[CH_W], xaR[RB], xaI[RB], ybR[CH_W], ybI[CH_W], yaR[RB], yaI[RB];
+#pragma unroll
+  for (int c = 0; c < CH_W; ++c) { xbR[c] = Bp[c][0]; xbI[c] = Bp[c][256]; }
+#pragma unroll
+  for (int m = 0; m < RB; ++m) { xaR[m] = Ap[m][0]; xaI[m] = Ap[m][256]; }
+  const int nit = 4 * Q0;   // (even)
+#define CH_BU_STEP(aR, aI, bR, bI, naR, naI, nbR, nbI, nx)                                                   \
+  {                                                                                                           \
+    const size_t off = (size_t)((nx) >> 2) * 512 + (size_t)((nx) & 3) * 64;                                   \
+    _Pragma("unroll") for (int c = 0; c < CH_W; ++c) { nbR[c] = Bp[c][off]; nbI[c] = Bp[c][off + 256]; }      \
+    _Pragma("unroll") for (int m = 0; m < RB; ++m) { naR[m] = Ap[m][off]; naI[m] = Ap[m][off + 256]; }        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    double sA[RB], dB[CH_W];                                                                                  \
+    _Pragma("unroll") for (int m = 0; m < RB; ++m) sA[m] = aR[m] + aI[m];                                     \
+    _Pragma("unroll") for (int c = 0; c < CH_W; ++c) dB[c] = bI[c] - bR[c];                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    /* P1 = re re, P2 = im im, P3 = (re + im)(im' - re'):  Re = P1 + P2,  -Im = P3 + P1 - P2 */               \
+    _Pragma("unroll") for (int m = 0; m < RB; ++m)                                                            \
+      _Pragma("unroll") for (int c = 0; c < CH_W; ++c) {                                                      \
+        cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bR[c], cR[m][c], 0, 0, 0);                     \
+        c3[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[m], bI[c], c3[m][c], 0, 0, 0);                     \
+        cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[m], dB[c], cI[m][c], 0, 0, 0);                     \
+      }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < nit; it += 2) {
+    CH_BU_STEP(xaR, xaI, xbR, xbI, yaR, yaI, ybR, ybI, it + 1)
+    const int nx2 = (it + 2 < nit) ? (it + 2) : (it + 1);
+    CH_BU_STEP(yaR, yaI, ybR, ybI, xaR, xaI, xbR, xbI, nx2)
+  }
+#undef CH_BU_STEP
+  // T[P][Q0+c] -= sum  (Re -= sum a conj(b) real part;  the second accumulator holds minus the imaginary part); the
+  // eight values of a tile are requested together
+#pragma unroll
+  for (int m = 0; m < RB; ++m) {
+    const int P = Pg + RS * m;
+#pragma unroll
+    for (int c = 0; c < CH_W; ++c) {
+      if (c >= Wc || Q0 + c > P) continue;   // (tile above the diagonal / beyond the last column)
+      double* Ct = T + tile_off(P, Q0 + c) + lq * 16 + lcol;
+      double oR[4], oI[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { oR[r] = Ct[64 * r]; oI[r] = Ct[256 + 64 * r]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Ct[64 * r] = oR[r] - (cR[m][c][r] + c3[m][c][r]);
+        Ct[256 + 64 * r] = oI[r] + (cI[m][c][r] + (cR[m][c][r] - c3[m][c][r]));
+      }
+    }
+  }
+}
 
 // T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); D0: 16*nt doubles (original diagonal, for the
 // collapsed-pivot check); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
+template <int NW>
 __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, double* __restrict__ D0,
-                                            int nt, int Kc, int nbk, double* lds, double* xs, int* fault) {
+                                            int nt, int Kc, int nbk, double* lds, double* xs, int* fault,
+                                            unsigned long long* dbg = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
+  // phase stamps of thread 0, slots 4-9 (diagnostic build -DEAQHM_EXPERIMENT_STAMPS only — compiled in they cost the
+  // large-frame kernel 5 % through its register allocation; tools/phase_probe_big.py)
+#ifndef EAQHM_EXPERIMENT_STAMPS
+#define CH_STAMP(ph) do { } while (0)
+#else
+  unsigned long long t_prev = (dbg && tid == 0) ? __builtin_amdgcn_s_memtime() : 0ull;
+#define CH_STAMP(ph)                                              \
+  do {                                                            \
+    if (dbg && tid == 0) {                                        \
+      const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+      atomicAdd(dbg + (ph), t_now - t_prev);                      \
+      t_prev = t_now;                                             \
+    }                                                             \
+  } while (0)
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int RB = (NW == 8) ? CH_RB : 1;   // tile rows per wave and register group of the block update (NW * RB rows per group)
+  constexpr int MB = (8 * CH_MB) / NW;        // tiles per wave, column and register group (48 rows per group)
+  static_assert(NW == 8 || NW == 12 || NW == 16, "tile_cholesky_memory: 8, 12 or 16 waves");
   double* Dc = lds;
   double* Zc = Dc + DG_TILE;
   double* WtR = Zc + DG_TILE;
@@ -545,7 +641,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
   double* LdR = WtI + TL_TILE;
   double* LdI = LdR + TL_TILE;
   double* trb = LdI + TL_TILE + (size_t)wave * 2 * TL_TILE;   // this wave's transposition buffer
-  double* zv = LdI + TL_TILE + 8 * 2 * TL_TILE;
+  double* zv = LdI + TL_TILE + NW * 2 * TL_TILE;
   double* xv = zv + 2 * 16 * CH_NTMAX;
   // original diagonal of the whole system (the collapsed-pivot check of diag_coop compares against it)
   for (int q = tid; q < 16 * nt; q += blockDim.x) {
@@ -563,100 +659,35 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
 #endif
     // ---- (1) block update of columns Q0 .. Q0+Wc-1 from the columns before the block.  Rows P = Q0 + wave + 8 x,
     //      CH_RB of them per register group; three accumulators per tile, three real products per complex one.
-    const int ngr = (nt - Q0 + 8 * CH_RB - 1) / (8 * CH_RB);
+    const int ngr = (nt - Q0 + NW * RB - 1) / (NW * RB);
     for (int g = 0; g < ngr; ++g) {
-      d4 cR[CH_RB][CH_W], cI[CH_RB][CH_W], c3[CH_RB][CH_W];
-#pragma unroll
-      for (int m = 0; m < CH_RB; ++m)
-#pragma unroll
-        for (int c = 0; c < CH_W; ++c) {
-          cR[m][c] = (d4){0, 0, 0, 0}; cI[m][c] = (d4){0, 0, 0, 0}; c3[m][c] = (d4){0, 0, 0, 0};
-        }
-      const int Pg = Q0 + wave + 8 * CH_RB * g;
-      if (Pg < nt) {
-        // software-pipelined over it = 4 j + ks: the operands of step it+1 are requested before the MFMAs of step it
-        // are issued (the tiles come from L2/HBM: a round trip per step would otherwise be exposed)
-        const double* Bp[CH_W];
-        const double* Ap[CH_RB];
-#pragma unroll
-        for (int c = 0; c < CH_W; ++c) Bp[c] = T + tile_off((c < Wc) ? (Q0 + c) : Q0, 0) + lq * 16 + lcol;
-#pragma unroll
-        for (int m = 0; m < CH_RB; ++m) Ap[m] = T + tile_off((Pg + 8 * m < nt) ? (Pg + 8 * m) : Pg, 0) + lq * 16 + lcol;
-        double bR[CH_W], bI[CH_W], aR[CH_RB], aI[CH_RB];
-#pragma unroll
-        for (int c = 0; c < CH_W; ++c) { bR[c] = Bp[c][0]; bI[c] = Bp[c][256]; }
-#pragma unroll
-        for (int m = 0; m < CH_RB; ++m) { aR[m] = Ap[m][0]; aI[m] = Ap[m][256]; }
-        const int nit = 4 * Q0;
-        for (int it = 0; it < nit; ++it) {
-          double nbR[CH_W], nbI[CH_W], naR[CH_RB], naI[CH_RB];
-          {   // tile j = it/4 of a row starts 512 j doubles after tile 0; k-step ks = it%4 is 64 doubles further
-            const int nx = (it + 1 < nit) ? (it + 1) : it;
-            const size_t off = (size_t)(nx >> 2) * 512 + (size_t)(nx & 3) * 64;
-#pragma unroll
-            for (int c = 0; c < CH_W; ++c) { nbR[c] = Bp[c][off]; nbI[c] = Bp[c][off + 256]; }
-#pragma unroll
-            for (int m = 0; m < CH_RB; ++m) { naR[m] = Ap[m][off]; naI[m] = Ap[m][off + 256]; }
-          }
-          __builtin_amdgcn_sched_barrier(0);   // the requests above stay ahead of the MFMAs below
-#pragma unroll
-          for (int m = 0; m < CH_RB; ++m) {
-            const int P = Pg + 8 * m;
-            if (P >= nt) continue;
-#pragma unroll
-            for (int c = 0; c < CH_W; ++c) {
-              if (c >= Wc || Q0 + c > P) continue;   // (tile above the diagonal / beyond the last column)
-              // P1 = re re, P2 = im im, P3 = (re + im)(im' - re'):  Re = P1 + P2,  -Im = P3 + P1 - P2
-              cR[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m], bR[c], cR[m][c], 0, 0, 0);
-              c3[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[m], bI[c], c3[m][c], 0, 0, 0);
-              cI[m][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[m] + aI[m], bI[c] - bR[c], cI[m][c], 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < CH_W; ++c) { bR[c] = nbR[c]; bI[c] = nbI[c]; }
-#pragma unroll
-          for (int m = 0; m < CH_RB; ++m) { aR[m] = naR[m]; aI[m] = naI[m]; }
-        }
-        // T[P][Q0+c] -= sum  (Re -= sum a conj(b) real part;  the second accumulator holds minus the imaginary part)
-#pragma unroll
-        for (int m = 0; m < CH_RB; ++m) {
-          const int P = Pg + 8 * m;
-          if (P >= nt) continue;
-#pragma unroll
-          for (int c = 0; c < CH_W; ++c) {
-            if (c >= Wc || Q0 + c > P) continue;
-            double* Ct = T + tile_off(P, Q0 + c);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int o = (lq + 4 * r) * 16 + lcol;
-              Ct[o] -= cR[m][c][r] + c3[m][c][r];
-              Ct[256 + o] += cI[m][c][r] + (cR[m][c][r] - c3[m][c][r]);
-            }
-          }
-        }
-      }
+      const int Pg = Q0 + wave + NW * RB * g;
+      if (Pg >= nt) continue;
+      if (RB == 2 && Pg + NW < nt) chol_block_unit<2, NW>(T, Q0, Wc, Pg, lq, lcol);
+      else chol_block_unit<1, NW>(T, Q0, Wc, Pg, lq, lcol);
     }
     __syncthreads();   // the block's tiles are up to date with every column before the block
+    CH_STAMP(4);
    }
    for (int Q = Q0; Q < Q0 + Wc; ++Q) {
-    // ---- (2) column Q: tiles P = Q + wave + 8 m, in groups of CH_MB per wave (registers); the first group holds the
+    // ---- (2) column Q: tiles P = Q + wave + NW m, in groups of MB per wave (registers); the first group holds the
     // diagonal tile, which is factorised before any panel tile is finished.  Only the block's own earlier columns
     // are still to be subtracted.
     const double* dref = D0 + 16 * Q;
-    const int ngroups = (nt - Q + 8 * CH_MB - 1) / (8 * CH_MB);
+    const int ngroups = (nt - Q + NW * MB - 1) / (NW * MB);
     for (int grp = 0; grp < ngroups; ++grp) {
-      const int Pb = Q + wave + 8 * CH_MB * grp;   // this wave's first tile of the group
-      d4 p1[CH_MB], p2[CH_MB], p3[CH_MB];
+      const int Pb = Q + wave + NW * MB * grp;   // this wave's first tile of the group
+      d4 p1[MB], p2[MB], p3[MB];
 #pragma unroll
-      for (int m = 0; m < CH_MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
+      for (int m = 0; m < MB; ++m) { p1[m] = (d4){0, 0, 0, 0}; p2[m] = (d4){0, 0, 0, 0}; p3[m] = (d4){0, 0, 0, 0}; }
       for (int j = Q0; j < Q; ++j) {
         const double* Bt = T + tile_off(Q, j);
         double bR[4], bI[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { const int o = (4 * ks + lq) * 16 + lcol; bR[ks] = Bt[o]; bI[ks] = Bt[256 + o]; }
 #pragma unroll
-        for (int m = 0; m < CH_MB; ++m) {
-          const int P = Pb + 8 * m;
+        for (int m = 0; m < MB; ++m) {
+          const int P = Pb + NW * m;
           if (P >= nt) continue;
           const double* At = T + tile_off(P, j);
 #pragma unroll
@@ -671,8 +702,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
       }
       // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3)
 #pragma unroll
-      for (int m = 0; m < CH_MB; ++m) {
-        const int P = Pb + 8 * m;
+      for (int m = 0; m < MB; ++m) {
+        const int P = Pb + NW * m;
         if (P >= nt) continue;
         const double* Ct = T + tile_off(P, Q);
 #pragma unroll
@@ -683,6 +714,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
           p1[m][r] = cr; p3[m][r] = ci;
         }
       }
+      CH_STAMP(5);
       if (grp == 0) {
         if (wave == 0) {   // the diagonal tile is this wave's first tile of the first group
 #pragma unroll
@@ -698,11 +730,12 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid, dref, (Q == nt - 1) ? 0 : 16, fault);   // ends with a barrier
 #endif
         for (int q = tid; q < 2 * TL_TILE; q += blockDim.x) WT[(size_t)Q * 2 * TL_TILE + q] = WtR[q];   // WtR | WtI contiguous
+        CH_STAMP(6);
       }
       // panel tiles: X = C W^H (three real products), stored k-major
 #pragma unroll
-      for (int m = 0; m < CH_MB; ++m) {
-        const int P = Pb + 8 * m;
+      for (int m = 0; m < MB; ++m) {
+        const int P = Pb + NW * m;
         if (P >= nt || P == Q) continue;
         double* tr = trb;
         double* ti = trb + TL_TILE;
@@ -729,8 +762,10 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
           Lt[256 + lcol * 16 + lq + 4 * r] = x3[r] - (x1[r] + x2[r]);
         }
       }
+      CH_STAMP(7);
     }
     __syncthreads();   // factor column visible to every wave; Dc / Wt reusable
+    CH_STAMP(8);
    }
   }
 
@@ -777,6 +812,8 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
     }
     __syncthreads();
   }
+  CH_STAMP(9);
+#undef CH_STAMP
 }
 
 }  // namespace eaqhm

@@ -29,8 +29,20 @@ namespace eaqhm {
 #define MF_A0_M 19   // adaptation 0 on chip: real systems of up to 19 tile rows (Kc + 1 <= 304)
 #define MF_A0_NCH 4
 #define MF_CI 8      // doubles of per-slot info: carries, window pointers, 1/(am_mid+eps), rho (prepare_slots)
+// workgroup of eaqhm_ls_mfma_kernel: MFK_WAVES waves with MF_NT base Gramian tiles per wave and pass, each tile with its
+// three weights (9 accumulators of 8 VGPRs) — 16 tiles per pass either way
+#ifndef MFK_WAVES
+#define MFK_WAVES 8
+#endif
+#define MFK_THREADS (64 * MFK_WAVES)
+// MF_FOURPROD: four real products per complex one on TWO accumulators per (tile, weight) instead of three products on
+// three — 12 MFMAs per tile and k-step instead of 9, 48 accumulator registers per tile instead of 72 (experiment: twelve
+// waves of 168 registers with two tiles each, 24 tiles per pass)
+#if MFK_WAVES == 12
+#define MF_FOURPROD 1
+#endif
 #ifndef MF_NT
-#define MF_NT 2      // base Gramian tiles per wave and pass, each with its three weights (9 accumulators of 8 VGPRs)
+#define MF_NT ((MFK_WAVES == 12) ? 2 : (16 / MFK_WAVES))
 #endif
 
 struct MfScratch {
@@ -57,10 +69,10 @@ __device__ inline void tile_of(int q, int& I, int& J) {
   J = q - I * (I + 1) / 2;
 }
 
-extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int plane, int min_nb, int a0_onchip) {
+extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(LsArgs A, int plane, int min_nb, int a0_onchip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (min_nb > 0 && A.cls[LS_BIG_CLASS] == 0) return;   // nothing left over by eaqhm_ls_tile_kernel (uniform across the grid)
-  const int tid = threadIdx.x, nt = MF_THREADS;
+  const int tid = threadIdx.x, nt = MFK_THREADS;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the unit bookkeeping in SGPRs
   const int Mmax = 2 * A.Kcmax;
@@ -83,6 +95,24 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     S.D0 = S.WT + (2 * (((size_t)A.Kcmax + 15) / 16) + 1) * 2 * TL_TILE;
   }
   const bool seeds = (A.mode == 1) && A.any_seed && (*A.any_seed != 0);
+  // phase stamps of thread 0 (diagnostic build -DEAQHM_EXPERIMENT_STAMPS only, see eaqhm_ls_chol.h; tools/phase_probe_big.py)
+#ifndef EAQHM_EXPERIMENT_STAMPS
+  unsigned long long* const dbg = nullptr;
+#define MF_STAMP(ph) do { } while (0)
+#define MF_STAMP_START() do { } while (0)
+#else
+  unsigned long long* dbg = uni(A.debug);
+  unsigned long long t_prev = 0;
+#define MF_STAMP_START() do { if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#define MF_STAMP(ph)                                              \
+  do {                                                            \
+    if (dbg && tid == 0) {                                        \
+      const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+      atomicAdd(dbg + (ph), t_now - t_prev);                      \
+      t_prev = t_now;                                             \
+    }                                                             \
+  } while (0)
+#endif
 
   // after eaqhm_ls_tile_kernel (min_nb > 0) only the frames of the last size class are left, usually none
   const int n_items = (min_nb > 0) ? A.cls[LS_BIG_CLASS] : A.n_frames;
@@ -99,13 +129,14 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     const int c = uni(A.frame_c[f]), wl = uni(A.frame_wl[f]), inst = uni(A.frame_inst[f]);
     if (min_nb == 0 && !frame_window_ok(A, c, wl)) continue;   // (counted by the classification kernel; class lists never hold such a frame)
     const int N = 2 * wl + 1, mid = wl;
+    MF_STAMP_START();
     const int n = uni((A.mode == 0) ? A.frame_K[f] : A.ncol[f]);
     const int Kc = 2 * n + 1, C1 = Kc + 1;
     const int nbk = (Kc + 15) >> 4, ntl = 2 * nbk + 1;   // stacked padded tile rows (eaqhm_ls_chol.h)
     const int nb = (C1 + 15) >> 4, C1p = nb << 4;
     const int ldx = C1p + ((nb & 1) ? 0 : 16);  // ≡ 16 (mod 32)
     const int ntiles = nb * (nb + 1) / 2;
-    const int npass = (ntiles + MF_WAVES * MF_NT - 1) / (MF_WAVES * MF_NT);
+    const int npass = (ntiles + MFK_WAVES * MF_NT - 1) / (MFK_WAVES * MF_NT);
     const double f0 = uni((A.mode == 0) ? A.frame_f0[f] : A.f0_stale);
     const int* mycols = (A.mode == 1) ? (A.cols + (size_t)f * A.Kmax) : nullptr;
     const int npairs = mid + 1;  // sample pairs (u, v) = (mid-d-1, mid+d), d = 0..mid (u = -1: the virtual sample before the window)
@@ -117,7 +148,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
     double* Xim = Xbase + (size_t)TSf * ldx;
 
     if (A.mode == 1)
-      prepare_slots<MF_CI, MF_WAVES>(A, S.Q, S.r, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, nchs);
+      prepare_slots<MF_CI, MFK_WAVES>(A, S.Q, S.r, Npad, ci, masks, gappy, mycols, n, N, mid, c, wl, seeds, lane, wave, nchs);
     // the factorisation and the slot set-up used the planes as work space: finite everywhere, padding columns zero
     for (int q = tid; q < 2 * plane; q += nt) Xbase[q] = 0.0;
     // right-hand-side tile row: zero, its diagonal tile the identity (row 0 is filled from the signal row below)
@@ -126,6 +157,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
       S.T[tile_off(ntl - 1, Qt) + e] = (Qt == ntl - 1 && e < 256 && (e >> 4) == (e & 15)) ? 1.0 : 0.0;
     }
     __syncthreads();
+    MF_STAMP(0);
 
     if (A.mode == 0) {
       // ---- adaptation 0: the stacked padded system straight from the Toeplitz tables (eaqhm_ls_common.h): no basis,
@@ -172,7 +204,11 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
       // every slot is one 16x16 tile of the base Gramian with all three weights: the operands are read once per k-step
       // for the three products, and every complex product is three real ones (P1 = re re, P2 = im im,
       // P3 = (re + im)(im' - re'):  Re = P1 + P2,  Im = P3 + P1 - P2): 9 MFMAs per tile and k-step instead of 12
+#ifdef MF_FOURPROD
+      d4 P1[MF_NT][3], P3[MF_NT][3];          // Re, Im
+#else
       d4 P1[MF_NT][3], P2[MF_NT][3], P3[MF_NT][3];
+#endif
       int tI[MF_NT], tJ[MF_NT];
       bool live[MF_NT];
 #pragma unroll
@@ -180,10 +216,12 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
           P1[sl][w] = (d4){0, 0, 0, 0};
+#ifndef MF_FOURPROD
           P2[sl][w] = (d4){0, 0, 0, 0};
+#endif
           P3[sl][w] = (d4){0, 0, 0, 0};
         }
-        const int x = (pass * MF_NT + sl) * MF_WAVES + wave;
+        const int x = (pass * MF_NT + sl) * MFK_WAVES + wave;
         live[sl] = x < ntiles;
         int I = 0, J = 0;
         tile_of(live[sl] ? x : 0, I, J);
@@ -253,6 +291,7 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
           Xre[row * ldx + XCOL(Kc, el)] = sv;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
         }
         __syncthreads();
+        MF_STAMP(1);
         // (touching the next chunk's track lines here, as the tile kernel does, costs 5 % in this kernel: 630 vs 598 ms)
         // ---- contraction of the chunk (only the k-steps that hold samples: the rest of the last chunk has weight 0)
         const int pcs = (npairs - d0 < PE) ? (npairs - d0) : PE;
@@ -278,6 +317,35 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
             rb += 4 * ldx;
             // all weighted operands first, then the MFMAs back to back: with a multiply in front of every MFMA a wave
             // issues one only every ~186 cycles (93 per SIMD with its two waves) instead of every ~141
+#ifdef MF_FOURPROD
+            double nI[MF_NT], bRw[MF_NT][3], bIw[MF_NT][3];
+#pragma unroll
+            for (int sl = 0; sl < MF_NT; ++sl) {
+              nI[sl] = -aI[sl];
+#pragma unroll
+              for (int w = 0; w < 3; ++w) {
+                const double wv = (w == 0) ? w0 : (w == 1) ? w1v : w2;
+                bRw[sl][w] = wv * bR[sl]; bIw[sl][w] = wv * bI[sl];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // Re += aR bR + aI bI,  Im += aR bI - aI bR  (conj(a) b): the two products of an accumulator are issued a
+            // round of the other accumulators apart
+#pragma unroll
+            for (int sl = 0; sl < MF_NT; ++sl) {
+              if (!live[sl]) continue;
+#pragma unroll
+              for (int w = 0; w < 3; ++w) {
+                P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[sl], bRw[sl][w], P1[sl][w], 0, 0, 0);
+                P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[sl], bIw[sl][w], P3[sl][w], 0, 0, 0);
+              }
+#pragma unroll
+              for (int w = 0; w < 3; ++w) {
+                P1[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[sl], bIw[sl][w], P1[sl][w], 0, 0, 0);
+                P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(nI[sl], bRw[sl][w], P3[sl][w], 0, 0, 0);
+              }
+            }
+#else
             double sA[MF_NT], bRw[MF_NT][3], bIw[MF_NT][3], dw[MF_NT][3];
 #pragma unroll
             for (int sl = 0; sl < MF_NT; ++sl) {
@@ -300,11 +368,13 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
                 P3[sl][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[sl], dw[sl][w], P3[sl][w], 0, 0, 0);
               }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
 #endif
         __syncthreads();
+        MF_STAMP(2);
       }
 
       // ---- accumulators -> tiles of the stacked padded system [[G0,G1^H],[G1,G2]] + RHS row (eaqhm_ls_chol.h).
@@ -319,7 +389,11 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int al = (lane >> 4) + 4 * rr, a = 16 * I + al;
+#ifdef MF_FOURPROD
+          const double gr = P1[sl][p][rr], gi = P3[sl][p][rr];
+#else
           const double gr = P1[sl][p][rr] + P2[sl][p][rr], gi = P3[sl][p][rr] + (P1[sl][p][rr] - P2[sl][p][rr]);
+#endif
           if (a == Kc) {   // signal row: conj(rhs) into row 0 of the RHS tile row, its energy on the diagonal
             if (b < Kc && p == 0) { double* t = S.T + tile_off(ntl - 1, J) + bl; t[0] = gr; t[256] = gi; }
             if (b < Kc && p == 1) { double* t = S.T + tile_off(ntl - 1, nbk + J) + bl; t[0] = gr; t[256] = gi; }
@@ -347,11 +421,14 @@ extern "C" __global__ void __launch_bounds__(MF_THREADS) eaqhm_ls_mfma_kernel(Ls
       }
     }
     __syncthreads();
+    MF_STAMP(3);
 
 #ifndef EAQHM_EXPERIMENT_NOCHOL   /* (timing experiment: the frame without its factorisation; wrong results) */
-    tile_cholesky_memory(S.T, S.WT, S.D0, ntl, Kc, nbk, Xbase, xs, A.fault);
+    tile_cholesky_memory<MFK_WAVES>(S.T, S.WT, S.D0, ntl, Kc, nbk, Xbase, xs, A.fault, dbg);
 #endif
+    MF_STAMP_START();
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
+    MF_STAMP(10);
   }
 }
 
@@ -419,7 +496,7 @@ int launch_ls_mfma(eaqhm_ctx* ctx, LsArgs A, int grid, int min_nb) {
     hipLaunchKernelGGL(eaqhm_ls_a0big_kernel, dim3(grid), dim3(MF_THREADS), a0_bytes, ctx->stream, A, min_nb, cursor);
     HIP_TRY(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MF_THREADS), lds_bytes, ctx->stream, A, plane, min_nb, a0_onchip);
+  hipLaunchKernelGGL(eaqhm_ls_mfma_kernel, dim3(grid), dim3(MFK_THREADS), lds_bytes, ctx->stream, A, plane, min_nb, a0_onchip);
   HIP_TRY(ctx, hipGetLastError());
   return EAQHM_OK;
 }
