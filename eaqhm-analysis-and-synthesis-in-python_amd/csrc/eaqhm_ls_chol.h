@@ -609,11 +609,12 @@ __device__ __attribute__((always_inline)) inline void chol_block_unit(double* __
 }
 
 // T: tiles; WT: nt * 2*TL_TILE doubles (W^H of every diagonal tile); D0: 16*nt doubles (original diagonal, for the
-// collapsed-pivot check); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out
+// collapsed-pivot check); lds: CH_LDS_DOUBLES; xs: 4*Kc doubles out (pair_n: column order of the caller, see the back
+// substitution)
 template <int NW>
 __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __restrict__ WT, double* __restrict__ D0,
                                             int nt, int Kc, int nbk, double* lds, double* xs, int* fault,
-                                            unsigned long long* dbg = nullptr) {
+                                            unsigned long long* dbg = nullptr, int pair_n = -1) {
   const int tid = threadIdx.x, lane = tid & 63, lcol = lane & 15, lq = lane >> 4;
   // phase stamps of thread 0, slots 4-9 (diagnostic build -DEAQHM_EXPERIMENT_STAMPS only — compiled in they cost the
   // large-frame kernel 5 % through its register allocation; tools/phase_probe_big.py)
@@ -793,7 +794,12 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
       if (k == 0) {
         xv[2 * i] = xr; xv[2 * i + 1] = xi;
         const int q = (P < nbk) ? (16 * P + i) : (16 * (P - nbk) + i);   // amplitudes, then slopes
-        if (q < Kc) { const int d = (P < nbk) ? q : (Kc + q); xs[2 * d] = xr; xs[2 * d + 1] = xi; }
+        if (q < Kc) {
+          // pair_n = n >= 0: the caller's columns are ordered [neg 0, pos 0, neg 1, pos 1, ..., DC]; xs is [neg | DC | pos]
+          const int qo = (pair_n < 0) ? q : ((q == 2 * pair_n) ? pair_n : ((q & 1) ? (pair_n + 1 + (q >> 1)) : (q >> 1)));
+          const int d = (P < nbk) ? qo : (Kc + qo);
+          xs[2 * d] = xr; xs[2 * d + 1] = xi;
+        }
       }
     }
     __syncthreads();

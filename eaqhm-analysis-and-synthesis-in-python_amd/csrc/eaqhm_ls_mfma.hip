@@ -228,6 +228,16 @@ extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(L
         tI[sl] = I; tJ[sl] = J;
       }
 
+      // The two columns of slot j sit next to each other (2j, 2j+1), so the tiles of this pass — lower-triangle tiles in
+      // row-major order up to tile row Ihi — only read the columns of the slots j < 8 (Ihi + 1): the others are not built
+      // (the passes of the first tile rows build a fraction of the basis; a fifth of the build over a frame)
+      int jmax;
+      {
+        const int xl = (((pass + 1) * MF_NT * MFK_WAVES < ntiles) ? ((pass + 1) * MF_NT * MFK_WAVES) : ntiles) - 1;
+        int Ihi, Jhi;
+        tile_of(xl, Ihi, Jhi);
+        jmax = uni((8 * (Ihi + 1) < n) ? (8 * (Ihi + 1)) : n);
+      }
       if (pass > 0) {   // the running sums start again at the window centre
         for (int j = tid; j < n; j += nt) { ci[j * MF_CI] = 0.0; ci[j * MF_CI + 1] = 0.0; }
         __syncthreads();
@@ -238,7 +248,7 @@ extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(L
         //      column cc of those two rows lives at XCOL(cc, el)
 #ifndef EAQHM_EXPERIMENT_NOBUILD   /* (timing experiment: stale basis rows; wrong results) */
 #pragma clang loop unroll(disable)
-        for (int idx = tid; idx < 16 * n; idx += nt) {
+        for (int idx = tid; idx < 16 * jmax; idx += nt) {
           const int el = idx & 15, j = idx >> 4, d = d0 + el;
           const bool act = (el < PE) && (d <= mid);
           const int u = mid - d - 1;
@@ -263,7 +273,7 @@ extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(L
           const double eps = 10e-5;
           double* xr = Xre + (2 * el) * ldx;
           double* xi = Xim + (2 * el) * ldx;
-          const int cpos = XCOL(n + 1 + j, el), cneg = XCOL(j, el);
+          const int cpos = XCOL(2 * j + 1, el), cneg = XCOL(2 * j, el);   // (column order: [neg 0, pos 0, neg 1, pos 1, ..., DC, signal])
           // positive column at t uses E1(t); negative column at t uses ratio[mirror+1] * E1(mirror) * rho
           if (u >= 0) {
             const double ru = (eps + au) * ainv, rv1 = (eps + av1) * ainv;
@@ -287,7 +297,7 @@ extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(L
           }
           const double nn = (double)(t - mid);
           Wp[row] = w0; Wp[32 + row] = w0 * nn; Wp[64 + row] = w0 * nn * nn;
-          Xre[row * ldx + XCOL(n, el)] = 1.0;  Xim[row * ldx + XCOL(n, el)] = 0.0;   // DC column
+          Xre[row * ldx + XCOL(2 * n, el)] = 1.0;  Xim[row * ldx + XCOL(2 * n, el)] = 0.0;   // DC column
           Xre[row * ldx + XCOL(Kc, el)] = sv;  Xim[row * ldx + XCOL(Kc, el)] = 0.0;  // signal column
         }
         __syncthreads();
@@ -424,7 +434,7 @@ extern "C" __global__ void __launch_bounds__(MFK_THREADS) eaqhm_ls_mfma_kernel(L
     MF_STAMP(3);
 
 #ifndef EAQHM_EXPERIMENT_NOCHOL   /* (timing experiment: the frame without its factorisation; wrong results) */
-    tile_cholesky_memory<MFK_WAVES>(S.T, S.WT, S.D0, ntl, Kc, nbk, Xbase, xs, A.fault, dbg);
+    tile_cholesky_memory<MFK_WAVES>(S.T, S.WT, S.D0, ntl, Kc, nbk, Xbase, xs, A.fault, dbg, (A.mode == 1) ? n : -1);
 #endif
     MF_STAMP_START();
     write_record(A, xs, sh, mycols, f, n, inst, c, f0, seeds);
