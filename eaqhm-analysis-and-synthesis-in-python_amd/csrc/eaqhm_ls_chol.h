@@ -701,18 +701,38 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
           }
         }
       }
-      // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3)
+      CH_STAMP(14);
+      // C = T[P][Q] - sum:  Re -= P1 + P2,  Im += P3 + P1 - P2   (kept in p1 / p3).  The eight values of the NEXT tile are
+      // requested before this one is combined: one exposed round trip per column instead of one per tile: 515 -> 500 ms.
+      // (The same arrangement for the A tiles of the j-loop above measured slower, 504.7 vs 499.7 ms, and for the
+      // write-back of the block update no different, 500.1.)
+      {
+        double oR[4], oI[4];
+        {
+          const double* Ct = T + tile_off((Pb < nt) ? Pb : (nt - 1), Q) + lq * 16 + lcol;
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const int P = Pb + NW * m;
-        if (P >= nt) continue;
-        const double* Ct = T + tile_off(P, Q);
+          for (int r = 0; r < 4; ++r) { oR[r] = Ct[64 * r]; oI[r] = Ct[256 + 64 * r]; }
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = (lq + 4 * r) * 16 + lcol;
-          const double cr = Ct[o] - (p1[m][r] + p2[m][r]);
-          const double ci = Ct[256 + o] + (p3[m][r] + (p1[m][r] - p2[m][r]));
-          p1[m][r] = cr; p3[m][r] = ci;
+        for (int m = 0; m < MB; ++m) {
+          const int P = Pb + NW * m, Pn = P + NW;
+          double nR[4] = {0, 0, 0, 0}, nI[4] = {0, 0, 0, 0};
+          if (m + 1 < MB && Pn < nt) {
+            const double* Ct = T + tile_off(Pn, Q) + lq * 16 + lcol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { nR[r] = Ct[64 * r]; nI[r] = Ct[256 + 64 * r]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (P < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double cr = oR[r] - (p1[m][r] + p2[m][r]);
+              const double ci = oI[r] + (p3[m][r] + (p1[m][r] - p2[m][r]));
+              p1[m][r] = cr; p3[m][r] = ci;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { oR[r] = nR[r]; oI[r] = nI[r]; }
         }
       }
       CH_STAMP(5);
@@ -726,6 +746,7 @@ __device__ inline void tile_cholesky_memory(double* __restrict__ T, double* __re
         }
         diag_init(Zc, tid);
         __syncthreads();
+        CH_STAMP(15);
         // the last tile row is the right-hand side (row 0) plus identity padding: no real unknown there
 #ifndef EAQHM_EXPERIMENT_NOCHOLDIAG
         diag_coop(Dc, Zc, WtR, WtI, LdR, LdI, tid, dref, (Q == nt - 1) ? 0 : 16, fault);   // ends with a barrier

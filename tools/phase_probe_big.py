@@ -33,4 +33,5 @@ names = ["set-up, slot preparation, clears", "basis build of a chunk (to its bar
 tot = sum(d[:11])
 for n, v in zip(names, d[:11]):
     print("%-62s %16d cycles  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
+print("   of which: in-block j-loop %d, tile load + combine %d (slot 5 above = the latter); barrier in front of diag_coop %d" % (d[14], d[5], d[15]))
 print("workload", wl, secs, "s, frames", eng.nf, "launches", launches, "cycles/frame", tot / max(1, launches * eng.nf))
