@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(512) rate(double* out, int iters, double x, un
 template <int MODE>
 static int run(const char* name, int per_trip, double* out, unsigned long long* clk, int ncu) {
   const int iters = 40000;
-  for (int wps = 1; wps <= 4; ++wps) {
-    int threads = (wps == 3) ? 768 : (wps == 4 ? 512 : 256 * wps), blocks = (wps == 4) ? 2 * ncu : ncu;
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    int threads = (wps == 4) ? 512 : 256 * wps, blocks = (wps == 4) ? 2 * ncu : ncu;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     rate<MODE><<<blocks, threads>>>(out, 100, 1.0, clk);
     hipDeviceSynchronize();
@@ -75,11 +75,9 @@ static int run(const char* name, int per_trip, double* out, unsigned long long* 
     rate<MODE><<<blocks, threads>>>(out, iters, 1.0, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
-    double ghz = (double)h[0] / (double)h[1] * 0.1;
-    printf("%-46s %d waves/SIMD: %6.1f cyc per MFMA per SIMD  (clock %.2f GHz, %.1f TFLOP/s)\n", name, wps,
-           ms * 1e-3 * ghz * 1e9 / ((double)wps * iters * per_trip), ghz,
-           (double)ncu * 4 * wps * iters * per_trip * 2048.0 / ms / 1e9);
+    // cycles at the nominal 2.4 GHz from the wall time of the launch (every CU busy, 4 SIMDs x wps waves each)
+    printf("%-46s %d waves/SIMD: %6.1f cyc per MFMA per SIMD at 2.4 GHz, %.1f TFLOP/s\n", name, wps,
+           ms * 1e-3 * 2.4e9 / ((double)wps * iters * per_trip), (double)ncu * 4 * wps * iters * per_trip * 2048.0 / ms / 1e9);
   }
   return 0;
 }
