@@ -25,7 +25,8 @@ def main(argv=None):
     ap.add_argument("--partials", type=int, default=0)
     ap.add_argument("--no-write", action="store_true")
     ap.add_argument("--track-budget-mb", type=float, default=0.0,
-                    help="long files: device memory for the dense tracks; 0 = keep them resident for the whole file")
+                    help="long files: device memory for the dense tracks (streamed in time blocks, same results); 0 = automatic: "
+                         "resident while they fit comfortably, streamed otherwise")
     a = ap.parse_args(argv)
     gender = a.gender
     if "," in gender:
@@ -35,7 +36,7 @@ def main(argv=None):
         a.wav, gender, step=a.step, maxAdpt=a.max_adpt, pitchPeriods=a.pitch_periods,
         analysisWindow=a.analysis_window, fullWaveform=not a.voiced_only, fc=a.fc, partials=a.partials,
         printPrompts=True, loadingScreen=False,
-        track_budget_bytes=int(a.track_budget_mb * 2 ** 20) if a.track_budget_mb > 0 else None)
+        track_budget_bytes=int(a.track_budget_mb * 2 ** 20) if a.track_budget_mb > 0 else "auto")
     if not a.no_write:
         fs, _ = wavfile.read(a.wav)
         out = a.wav[:len(a.wav) - 4] + "_reconstructed.wav"

@@ -181,6 +181,16 @@ def srer_from_limbs(limbs, n, std_det):
         return np.float64(20.0) * np.log10(np.float64(std_det) / np.sqrt(var))
 
 
+def auto_track_budget(resident_bytes, free_bytes):
+    """The `track_budget_bytes="auto"` rule: keep the dense tracks resident (None) while they take less than 40 % of the
+    free device memory — the signal, the reconstructions, the records and the library's scratch need room too —,
+    otherwise stream them in time blocks under 15 % of it, at least 256 MiB, at most 4 GiB (beyond that more blocks are
+    no slower: DESIGN.md section 6.2)."""
+    if free_bytes is None or resident_bytes <= 0.4 * free_bytes:
+        return None
+    return int(min(max(0.15 * free_bytes, 256 * 2 ** 20), 4 * 2 ** 30))
+
+
 class DeviceAnalysis:
     """Buffers + launch sequence of one analysis run on one GPU (rank).
 
@@ -267,6 +277,11 @@ class DeviceAnalysis:
         self.any_seed = torch.zeros(1, dtype=i32, device=dev)
 
         # time blocks and the dense tracks (functions.py:159-160) — harmonic-major, [Kmax][samples of the window]
+        if isinstance(track_budget_bytes, str):
+            if track_budget_bytes != "auto":
+                raise ValueError("track_budget_bytes: a byte count, None or 'auto'")
+            free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
+            track_budget_bytes = auto_track_budget(self.TRACK_BYTES_PER_CELL * K * max(self.t_hi - self.t_lo, 0), free)
         self.blocks = self._plan_blocks(track_budget_bytes)
         self.streaming = track_budget_bytes is not None
         if self.streaming:

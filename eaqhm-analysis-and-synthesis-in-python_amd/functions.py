@@ -66,7 +66,7 @@ def _slot_arrays(active, *fields):
 
 
 def _prepare(speechFile, gender, step, maxAdpt, pitchPeriods, analysisWindow, fullWaveform, fc, partials,
-             pitch_track, device_index, track_budget_bytes=None):
+             pitch_track, device_index, track_budget_bytes="auto"):
     """functions.py:86-146: everything before the adaptation loop -> (plan, engine)."""
     fs, s = prologue.read_signal(speechFile, fc)                                 # functions.py:86-91
     length = len(s)
@@ -91,7 +91,7 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
                               maxAdpt: int = 10, pitchPeriods: int = 3, analysisWindow: int = 32,
                               fullWaveform: bool = True, fc: int = 0, partials: int = 0,
                               printPrompts: bool = True, loadingScreen: bool = True, *,
-                              pitch_track=None, device_index: int = 0, track_budget_bytes=None,
+                              pitch_track=None, device_index: int = 0, track_budget_bytes="auto",
                               det_format: str = "structs", _return_engine: bool = False):
     """Adaptive quasi-harmonic analysis/resynthesis of a mono 16-bit .wav on an MI355X.
 
@@ -105,7 +105,8 @@ def eaQHMAnalysisAndSynthesis(speechFile: str, gender: str or tuple = 'other', s
       track_budget_bytes  long files: bytes the dense am/fm tracks (and their zero counts) may occupy on the device.
                     None keeps them resident for the whole file (the reference keeps seven (L, Kmax) arrays,
                     functions.py:159-171); with a budget the frames are worked off in time blocks whose tracks are
-                    regenerated from the frame-centre records — same results, bit for bit
+                    regenerated from the frame-centre records — same results, bit for bit.  "auto" (default): resident
+                    while they take less than 40 % of the free device memory, else streamed (engine.auto_track_budget)
       det_format    "structs" (default): DetComponents is the reference's list of Deterministic objects
                     (functions.py:404-411).  "arrays": a dict of NumPy arrays instead — ti, isSpeech, isVoiced (per
                     instant), a0 (No_ti,), amplitudes / frange / pk (No_ti, Kmax; zero where a slot is inactive) — for

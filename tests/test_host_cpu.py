@@ -227,6 +227,36 @@ def test_srer_from_limbs_semantics():
     assert not (np.float64(np.nan) <= np.float64(1.0)) and np.float64(np.inf) <= np.float64(np.inf)
 
 
+def test_auto_track_budget_rule():
+    """track_budget_bytes="auto" (the drop-in's default): resident while the dense tracks take less than 40 % of the
+    free device memory, else a budget between 256 MiB and 4 GiB; without a device (CPU stand-in) resident."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_backend import OracleBackend
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan, auto_track_budget
+    from eaqhm_amd.synth import synth_speech_int16
+    GiB = 2 ** 30
+    assert auto_track_budget(54 * GiB, 280 * GiB) is None                  # 60 min @16 kHz on an empty MI355X: resident
+    assert auto_track_budget(217 * GiB, 280 * GiB) == 4 * GiB              # 4 h @16 kHz: streamed, capped
+    assert auto_track_budget(3 * GiB, 4 * GiB) == int(0.15 * 4 * GiB)      # a crowded device
+    assert auto_track_budget(900 * 2 ** 20, GiB) == 256 * 2 ** 20          # never below 256 MiB
+    assert auto_track_budget(10 * GiB, None) is None                       # nothing known about the device
+    torch.set_num_threads(2)
+    fs = 16000
+    s = synth_speech_int16(0.3, fs) / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    grid = prologue.resample_track(np.column_stack([t, _pitch_profile(t, "true")]),
+                                   np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    prologue.apply_full_waveform(frames, len(s), 480)
+    plan = FramePlan(len(s), fs, grid, frames, fstep, 15, 3, 32, 0)
+    eng = DeviceAnalysis(s, s, plan, 100, 1, ctx=OracleBackend(), track_budget_bytes="auto")
+    assert not eng.streaming and len(eng.blocks) == 1
+    with pytest.raises(ValueError):
+        DeviceAnalysis(s, s, plan, 100, 1, ctx=OracleBackend(), track_budget_bytes="all of it")
+
+
 def test_time_block_streaming_matches_resident_run_host_logic():
     """SURVEY §8f row 4 (long files): with a track budget the frames are worked off in time blocks whose dense tracks
     are regenerated from the records; the host logic (block plan, windows, seeding flags, stop rule) with the oracle
