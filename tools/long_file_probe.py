@@ -1,6 +1,6 @@
 """Long files on one MI355X: the 60 s synthetic workload tiled to `minutes` minutes, analysed with
 the dense tracks streamed in time blocks under a byte budget (engine.DeviceAnalysis(track_budget_bytes=...)).
-    python tools/long_file_probe.py <synth16k_60s|synth48k_60s> <minutes> <track budget MB> [--also-resident] [--max-adpt N]
+    python tools/long_file_probe.py <synth16k_60s|synth48k_60s> <minutes> <track budget MB | auto> [--also-resident] [--max-adpt N]
 Prints one JSON line: frames/s of the adaptation loops, SRER list, time blocks, peak device memory of the engine's
 buffers, and — with --also-resident — whether the resident run gives bit for bit the same SRER list and records."""
 import json, os, sys, time
@@ -12,7 +12,8 @@ from eaqhm_amd import prologue
 from eaqhm_amd.engine import DeviceAnalysis, FramePlan
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-wl, minutes, budget_mb = args[0], int(args[1]), float(args[2])
+wl, minutes = args[0], int(args[1])
+budget = "auto" if args[2] == "auto" else int(float(args[2]) * 2 ** 20)
 max_adpt = int(sys.argv[sys.argv.index("--max-adpt") + 1]) if "--max-adpt" in sys.argv else 1
 fs, s1, track = bench.load_signal(wl)
 grid1 = prologue.resample_track(track, np.arange(0, len(s1) - 1, round(fs * 5 / 1000)) / fs)
@@ -51,8 +52,8 @@ def run(budget):
     return res
 
 
-out["streaming"] = run(int(budget_mb * 2 ** 20))
-out["streaming"]["budget_bytes"] = int(budget_mb * 2 ** 20)
+out["streaming"] = run(budget)
+out["streaming"]["budget_bytes"] = budget
 out["dense_tracks_if_resident_bytes"] = int(2 * 8 * plan.Kmax * plan.L)
 out["reference_seven_arrays_bytes"] = int(7 * 8 * plan.Kmax * plan.L)
 if "--also-resident" in sys.argv:
