@@ -20,29 +20,60 @@
 
 namespace eaqhm {
 
-// entry (gi, gj) of system `sys` (0 even, 1 odd), order Kc + 1 with the right-hand side as row / column Kc
-__device__ __attribute__((noinline)) double a0_entry(const double* tab, int TB, double ssq, int sys, int gi, int gj, int K, int Kc) {
-  if (gi > Kc || gj > Kc) return (gi == gj) ? 1.0 : 0.0;      // identity padding behind the right-hand side
-  if (gi == Kc && gj == Kc) return ssq;
-  const double* c0 = tab; const double* s1 = tab + TB; const double* c2 = tab + 2 * TB;
-  if (gi == Kc || gj == Kc) {                                  // sum w^2 s f(n)
-    const int e = (gi == Kc) ? gj : gi;
-    if (sys == 0) return (e <= K) ? tab[3 * TB + e] : tab[6 * TB + (e - K)];        // Re r0[k] | Im r1[k]
-    return (e < K) ? tab[4 * TB + (e + 1)] : tab[5 * TB + (e - K)];                 // Im r0[k] | Re r1[k]
+// Entries (gi0 + 4 r, gj), r = 0..3 — the four values of one lane of a 16x16 tile — of system `sys` (0 even, 1 odd), order
+// Kc + 1 with the right-hand side as row / column Kc.  Branch-free: every entry is  0.5 (s1 T[i1] + s2 T[i2])  of one
+// table, or one table value (right-hand side), or a constant (padding); the lanes of a tile differ in which, so the case
+// distinctions are selects, all the table reads of the four entries are in flight together, and the constants come last.
+// (Round 2's version was a branchy function per entry: 28 calls per lane of the 7-tile budget, each with its own exposed
+// LDS round trips and divergent paths — a fifth of the adaptation-0 launch.)
+__device__ __attribute__((noinline)) d4 a0_entry4(const double* tab, int TB_, double ssq, int sys_, int gi0, int gj, int K_, int Kc_) {
+  const int TB = uni(TB_), sys = uni(sys_), K = uni(K_), Kc = uni(Kc_);   // wave-uniform: the case distinctions on them are scalar
+  // (integer arithmetic instead of selects: the compiler turns nested selects into exec-mask branches)
+  const int split = K + 1 - sys;
+  const int tj = (gj >= split) ? 1 : 0;
+  const int l = gj - tj * K + sys * (1 - tj);      // harmonic number: even: k | k (n sin k), odd: k + 1 (sin) | k (n cos)
+  const int sg = 1 - 2 * sys;
+  int i1[4], i2[4];
+  double s2[4];
+  bool plain[4], rhs[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = gi0 + 4 * r;
+    const int ti = (gi >= split) ? 1 : 0;
+    const int k = gi - ti * K + sys * (1 - ti);
+    const int df = k - l, d = (df < 0) ? -df : df, sm = k + l;
+    // mixed products: harmonic of the plain function kp, of the n-times one lp; signed difference dd
+    const int kp = k + ti * (l - k), lp = l + ti * (k - l);
+    const int dd = sg * (lp - kp), ad = (dd < 0) ? -dd : dd;
+    const int same = 1 - (ti ^ tj);
+    // table: c0 (both plain), c2 (both n-times), s1 (mixed: s1[sm] + sgn(dd) s1[|dd|], s1[0] = 0)
+    const int base = same * ti * 2 * TB + (1 - same) * TB;
+    const int e = (gi == Kc) ? gj : gi;                      // the unknown a right-hand-side entry belongs to
+    // sum w^2 s f(n):  even: Re r0[k] | Im r1[k],  odd: Im r0[k] | Re r1[k]
+    const int hi = (e >= split) ? 1 : 0;                     // even: e > K, odd: e >= K
+    const int rq = (3 + sys + hi * (3 - 2 * sys)) * TB + e - hi * K + sys * (1 - hi);
+    const bool inside = (gi < Kc) && (gj < Kc);
+    const bool isr = !inside && gi <= Kc && gj <= Kc && (gi != gj);
+    i1[r] = inside ? (base + sm + same * (d - sm)) : (isr ? rq : 0);
+    i2[r] = inside ? (base + ad + same * (sm - ad)) : 0;
+    // cos cos | sin sin: c0[d] +- c0[sm];  n sin n sin | n cos n cos: c2[d] -+ c2[sm];  mixed: s1[sm] + sgn(dd) s1[|dd|]
+    const int sig = same * (1 - 2 * (sys ^ ti)) + (1 - same) * ((dd < 0) ? -1 : 1);
+    s2[r] = (double)sig;
+    plain[r] = inside;
+    rhs[r] = isr;
   }
-  // type 0: plain function (cos / sin), type 1: n times the other one (n sin / n cos); harmonic numbers k, l
-  const int split = (sys == 0) ? K + 1 : K;
-  const int ti = (gi >= split) ? 1 : 0, tj = (gj >= split) ? 1 : 0;
-  const int k = (sys == 0) ? (ti ? gi - K : gi) : (ti ? gi - K : gi + 1);
-  const int l = (sys == 0) ? (tj ? gj - K : gj) : (tj ? gj - K : gj + 1);
-  const int d = (k > l) ? k - l : l - k, sm = k + l;
-  if (ti == 0 && tj == 0) return 0.5 * ((sys == 0) ? (c0[d] + c0[sm]) : (c0[d] - c0[sm]));   // cos cos | sin sin
-  if (ti == 1 && tj == 1) return 0.5 * ((sys == 0) ? (c2[d] - c2[sm]) : (c2[d] + c2[sm]));   // n sin n sin | n cos n cos
-  // mixed: even: cos(k') n sin(l') = n (sin((l'+k')x) + sin((l'-k')x))/2;  odd: sin(k') n cos(l') = n (sin((k'+l')x) + sin((k'-l')x))/2
-  const int kp = ti ? l : k, lp = ti ? k : l;      // kp: harmonic of the plain function, lp: of the n-times one
-  const int dd = (sys == 0) ? (lp - kp) : (kp - lp);
-  const double sd = (dd > 0) ? s1[dd] : (dd < 0) ? -s1[-dd] : 0.0;
-  return 0.5 * (s1[sm] + sd);
+  double v1[4], v2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v1[r] = tab[i1[r]]; v2[r] = tab[i2[r]]; }
+  d4 out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = gi0 + 4 * r;
+    const double gen = 0.5 * (v1[r] + s2[r] * v2[r]);
+    const double pad = (gi > Kc || gj > Kc) ? ((gi == gj) ? 1.0 : 0.0) : ssq;   // identity padding behind the right-hand side | (Kc, Kc)
+    out[r] = plain[r] ? gen : (rhs[r] ? v1[r] : pad);
+  }
+  return out;
 }
 
 // LDS doubles a0_frame<., M, PAR> needs (TB: table stride >= 2 K + 2, NCH: chunks of the table sums, WP >= wl + 1,
@@ -111,6 +142,7 @@ __device__ __attribute__((noinline)) void a0_frame(const LsArgs& A, double* lds_
   A0_STAMP(0);
   toeplitz_tables(tab, part, W2, PA, PB, sh, win, sig, K, wl, f0 * (2.0 * M_PI / uni(A.fs)), tid, TB, NCH);
   const double ssq = sh[0];
+  A0_STAMP(1);
 
   // this wave's tiles of its system (numbered column by column, tile y on wave y % WPS, slot y / WPS)
   int tP[NS], tQ[NS];
@@ -136,9 +168,7 @@ __device__ __attribute__((noinline)) void a0_frame(const LsArgs& A, double* lds_
     if (tid < PAR) flags[tid] = 0;
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[sl][r] = live[sl] ? a0_entry(tab, TB, ssq, sys, 16 * tP[sl] + lq + 4 * r, 16 * tQ[sl] + lcol, K, Kc) : 0.0;
+      acc[sl] = live[sl] ? a0_entry4(tab, TB, ssq, sys, 16 * tP[sl] + lq, 16 * tQ[sl] + lcol, K, Kc) : (d4){0, 0, 0, 0};
       if (live[sl] && tP[sl] == tQ[sl]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)

@@ -133,7 +133,7 @@ __device__ inline double window_value(int blackman, int u, int N) {
 #define TZ_NQ 7       // c0, s1, c2, Re r0, Im r0, Re r1, Im r1
 __device__ inline void toeplitz_tables(double* tab, double* part, double* W2, double* PA, double* PB, double* ssq,
                                        const double* win, const double* sig, int n, int wl, double theta, int tid,
-                                       int TB, int NCH) {
+                                       int TB, int NCH_) {
   const int mid = wl, nthr = blockDim.x;
   for (int t = tid; t <= wl; t += nthr) {
     const double w = win[mid + t], w2 = w * w, sp = sig[mid + t], sm = sig[mid - t];
@@ -152,7 +152,18 @@ __device__ inline void toeplitz_tables(double* tab, double* part, double* W2, do
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
     if (tid == 0) ssq[0] = e;
   }
-  const int nm = 2 * n + 1, CL = (wl + NCH - 1) / NCH;
+  // chunks of the t range: as many (up to NCH_) as make rounds-of-tasks x terms-per-task smallest — 8 chunks of 65 sums are
+  // 520 tasks for 512 threads, two rounds of 15 terms where 7 chunks give one of 18
+  const int nm = 2 * n + 1;
+  int NCH = 1;
+  {
+    int best = 0x7fffffff;
+    for (int q = 1; q <= NCH_; ++q) {
+      const int cost = ((nm * q + nthr - 1) / nthr) * ((wl + q - 1) / q + 4);   // (+4: the seeds of a task)
+      if (cost < best) { best = cost; NCH = q; }
+    }
+  }
+  const int CL = (wl + NCH - 1) / NCH;
   for (int task = tid; task < nm * NCH; task += nthr) {
     const int ch = task / nm, m = task - ch * nm;
     const int t0 = 1 + ch * CL, t1 = (t0 + CL - 1 < wl) ? (t0 + CL - 1) : wl;
