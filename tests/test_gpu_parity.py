@@ -397,6 +397,54 @@ def test_other_sampling_rates_against_oracle(amd, fs, dur, gender):
     assert np.abs(eng.final_arrays()["s_recon"] - ref["s_recon"]).max() <= 1e-8
 
 
+def test_pitch_glide_across_the_kernel_boundary(amd):
+    """A glide from 130 to 200 Hz at 16 kHz: the systems shrink from 16 tile rows to 10 in the course of the file, so one
+    launch holds frames of the large-frame kernels (more than 13 tile rows: eaqhm_ls_a0big_kernel / eaqhm_ls_mfma_kernel
+    as the tile kernel's left-over class) next to frames of four size classes of the tile kernel.  Against the oracle."""
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    fs, n = 16000, 11200
+    rng = np.random.default_rng(11)
+    t = np.arange(n) / fs
+    f0 = 130.0 + 70.0 * t / t[-1]
+    phi = 2 * np.pi * np.cumsum(f0) / fs
+    x = np.zeros(n)
+    for k in range(1, 40):
+        x += k ** -1.1 * np.cos(k * phi + rng.uniform(0, 2 * np.pi)) * (k * f0 < 0.47 * fs)
+    x += rng.standard_normal(n) * np.sqrt(np.mean(x ** 2)) * 10 ** (-50 / 20)
+    s = np.round(0.25 * x / np.abs(x).max() * 32767) / 32768.0
+    tt = np.arange(0, n / fs, 0.001)
+    track = np.column_stack([tt, 130.0 + 70.0 * tt / t[-1], np.ones_like(tt)])
+    grid = prologue.resample_track(track, np.arange(0, n - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "other")
+    for fr in frames:
+        fr.isSpeech = fr.isVoiced = True
+    ti5 = np.array([f.ti for f in frames])
+    ones = np.ones(len(frames))
+    ref = O.analyse(s, fs, grid, ti5, ones, ones, fstep, f0min=70, maxAdpt=2, step=15, pitchPeriods=3, analysisWindow=32,
+                    partials=0)
+    plan = FramePlan(n, fs, grid, frames, fstep, 15, 3, 32, 0)
+    rows = (2 * (2 * plan.frame_K + 1) + 1 + 15) // 16
+    assert rows.max() > 13 and rows.min() <= 11 and len(np.unique(rows)) >= 5
+    eng = DeviceAnalysis(s, s, plan, 70, 2)
+    eng.run()
+    assert eng.ctx.ls_faults() == (0, 0, 0)
+    fin = eng.final_arrays()
+    assert len(eng.SRER) == len(ref["SRER"])
+    assert np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max() < TOL_SRER_DB
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9
+    m = ref["am"] != 0
+    assert np.mean((fin["am"] != 0) == m) >= 0.999
+    both = m & (fin["am"] != 0)
+    assert np.abs(fin["am"][both] - ref["am"][both]).max() <= TOL_AM_REL * ref["am"].max()
+    assert np.abs(fin["fm"][both] - ref["fm"][both]).max() <= TOL_FM_HZ
+    strong = both & (ref["am"] > 1e-6 * ref["am"].max())
+    assert np.abs(wrap(fin["pk"][strong] - ref["pk"][strong])).max() <= TOL_PH_RAD
+    record_measurement("pitch_glide_across_kernels", tile_rows=[int(rows.min()), int(rows.max())],
+                       srer_abs_diff_db=float(np.abs(np.array(eng.SRER) - np.array(ref["SRER"])).max()))
+
+
 def test_long_windows_against_oracle(amd):
     """A low voice at 32 kHz (f0 86-94 Hz, 'male' limits): windows of 1020-1120 samples — longer than the 1024-sample
     chunks of the zero counts and than the 16 x 64-sample masks the register-resident kernel is laid out for — and
