@@ -397,6 +397,54 @@ def test_other_sampling_rates_against_oracle(amd, fs, dur, gender):
     assert np.abs(eng.final_arrays()["s_recon"] - ref["s_recon"]).max() <= 1e-8
 
 
+@pytest.mark.parametrize("case", ["too_short", "two_frames", "digital_silence", "silence_then_speech", "constant"])
+def test_degenerate_inputs_like_the_oracle(amd, case):
+    """Inputs at the edge of the domain, each against the oracle: a file too short for any analysed frame (no frames, SRER
+    0 dB: the reconstruction is zero), one with a handful of frames, digital silence (every SRER nan: 0 / 0 in
+    functions.py:388, nothing accepted), silence followed by speech, and a constant.  The constant is the one documented
+    divergence: its partials are rounding noise, the frequency tracks derived from them make the systems of adaptation 1
+    numerically singular — the reference's inv() returns noise (SRER -inf: the target's variance is zero), this
+    implementation reports the Cholesky breakdown as LinAlgError."""
+    import warnings
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.engine import DeviceAnalysis, FramePlan
+    from eaqhm_amd.synth import synth_speech_int16
+    fs = 16000
+    x = synth_speech_int16(0.5, fs) / 32768.0
+    s = {"too_short": x[:800], "two_frames": x[:1060], "digital_silence": np.zeros(4800),
+         "silence_then_speech": np.concatenate((np.zeros(3000), x[:5000])), "constant": np.full(4800, 0.1)}[case]
+    n = len(s)
+    tt = np.arange(0, n / fs, 0.001)
+    track = np.column_stack([tt, np.full(len(tt), 200.0), np.ones_like(tt)])
+    gt = np.arange(0, n - 1, round(fs * 5 / 1000)) / fs
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # log10(0), 0 / 0 of the silent cases, as in the reference
+        ti5, sp, vo, fstep_o = O.voiced_unvoiced_frames(s, fs, "female")
+        ref = O.analyse(s, fs, O.get_linear(track, gt), ti5, sp, vo, fstep_o, f0min=160, maxAdpt=1)
+        grid = prologue.resample_track(track, gt)
+        frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+        prologue.apply_full_waveform(frames, n, 480)
+        plan = FramePlan(n, fs, grid, frames, fstep, 15, 3, 32, 0)
+        eng = DeviceAnalysis(s, s, plan, 160, 1)
+        if case == "constant":
+            assert np.isneginf(ref["SRER"]).all()
+            with pytest.raises(np.linalg.LinAlgError):
+                eng.run()
+            return
+        eng.run()
+    fin = eng.final_arrays()
+    assert eng.ctx.ls_faults() == (0, 0, 0)
+    assert (case != "too_short") or plan.n_frames == 0
+    srer, want = np.array(eng.SRER, dtype=np.float64), np.array(ref["SRER"], dtype=np.float64)
+    assert len(srer) == len(want) and np.array_equal(np.isnan(srer), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.abs(srer[ok] - want[ok]).max(initial=0.0) < TOL_SRER_DB
+    assert np.array_equal(fin["am"] != 0, ref["am"] != 0)
+    assert np.abs(fin["s_recon"] - ref["s_recon"]).max() <= 1e-9
+    assert np.abs(fin["am"] - ref["am"]).max(initial=0.0) <= TOL_AM_REL * max(ref["am"].max(initial=0.0), 1e-300)
+
+
 def test_pitch_glide_across_the_kernel_boundary(amd):
     """A glide from 130 to 200 Hz at 16 kHz: the systems shrink from 16 tile rows to 10 in the course of the file, so one
     launch holds frames of the large-frame kernels (more than 13 tile rows: eaqhm_ls_a0big_kernel / eaqhm_ls_mfma_kernel
