@@ -321,7 +321,7 @@ def _pitch_profile(t, profile):
 
 
 # ----------------------------------------------------------------------------- world_size = 2 over gloo
-def _sharded_worker(rank, world, port, out_path, profile="true"):
+def _sharded_worker(rank, world, port, out_path, profile="true", dur=0.62):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -335,7 +335,7 @@ def _sharded_worker(rank, world, port, out_path, profile="true"):
     from threadpoolctl import threadpool_limits
     threadpool_limits(limits=2)          # two ranks share the CI container's 8 cores
     fs = 16000
-    s = synth_speech_int16(0.62, fs) / 32768.0
+    s = synth_speech_int16(max(dur, 0.3), fs)[:int(dur * fs)] / 32768.0
     t = np.arange(0, len(s) / fs, 0.001)
     f0 = _pitch_profile(t, profile)
     grid = prologue.resample_track(np.column_stack([t, f0]), np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
@@ -384,6 +384,31 @@ def test_two_rank_gloo_matches_single_process(tmp_path, world, profile):
     assert np.abs(got["am"] - ref["am"]).max() < 1e-12 * lo and np.abs(got["fm"] - ref["fm"]).max() < 1e-7 * lo
     assert np.abs(got["pk"] - ref["pk"]).max() < 1e-9 * lo and np.abs(got["a0"] - ref["a0"]).max() < 1e-12 * lo
     assert 0 < int(got["n_frames_rank0"]) < ref["n_ls_frames"]      # rank 0 analysed only its share
+
+
+@pytest.mark.slow
+def test_more_ranks_than_work_gloo(tmp_path):
+    """Four ranks on a file with a handful of analysed frames: ranges shorter than the boundary margin (the exchange falls
+    back to whole rows) and ranks that may own no frame at all — same result as the single-process oracle."""
+    import torch.multiprocessing as mp
+    import eaqhm_oracle as O
+    from eaqhm_amd import prologue
+    from eaqhm_amd.synth import synth_speech_int16
+    out, dur, fs = str(tmp_path / "rank0.npz"), 0.075, 16000
+    mp.spawn(_sharded_worker, args=(4, 31000 + os.getpid() % 2000, out, "true", dur), nprocs=4, join=True)
+    got = np.load(out)
+    s = synth_speech_int16(0.3, fs)[:int(dur * fs)] / 32768.0
+    t = np.arange(0, len(s) / fs, 0.001)
+    grid = prologue.resample_track(np.column_stack([t, _pitch_profile(t, "true")]),
+                                   np.arange(0, len(s) - 1, round(fs * 5 / 1000)) / fs)
+    frames, fstep = prologue.voiced_unvoiced_frames(s, fs, "female")
+    ref = O.analyse(s, fs, grid, np.array([f.ti for f in frames]), np.array([float(f.isSpeech) for f in frames]),
+                    np.array([float(f.isVoiced) for f in frames]), fstep, f0min=100, maxAdpt=2)
+    assert 0 < ref["n_ls_frames"] // len(ref["SRER"]) < 40          # a handful of frames for four ranks
+    assert len(got["SRER"]) == len(ref["SRER"])
+    assert np.abs(got["SRER"] - np.array(ref["SRER"])).max() < 1e-9
+    assert np.abs(got["s_recon"] - ref["s_recon"]).max() < 1e-11
+    assert np.array_equal(got["am"] != 0, ref["am"] != 0) and np.abs(got["am"] - ref["am"]).max() < 1e-12
 
 
 def test_swipe_matches_reference_tracks(sa19_golden, sa19_signal):
