@@ -32,12 +32,13 @@
 #include "eaqhm_ls_common.h"
 #include "eaqhm_ls_chol.h"
 #include "eaqhm_ls_a0.h"
+#include "eaqhm_ls_tilemap.h"
 
 namespace eaqhm {
 
 
 // wave that owns the diagonal tile (jb, jb): see the ownership rules in tile_frame
-#define DIAG_OWNER(jb, nt) ((((jb) * (nt) - (jb) * ((jb) - 1) / 2)) % TL_CW)
+#define DIAG_OWNER(jb, nt) ((int)TL_DIAG[nt][jb])
 #define TL_THREADS 512
 #define TL_WAVES 8
 #define TL_CW 8         // all waves own tiles
@@ -149,18 +150,14 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
       accR[sl] = (d4){0, 0, 0, 0};
       accI[sl] = (d4){0, 0, 0, 0};
       if (sl < NM3) acc3[sl] = (d4){0, 0, 0, 0};
-      // Ownership: tiles numbered column by column, x = Q nt - Q(Q-1)/2 + (P - Q), tile x on wave x % 8, slot x / 8.
-      // The tiles of one tile column — the panel of a stage — then sit on consecutive waves, and so do the columns of
-      // the trailing matrix: both phases of every stage are balanced to within one tile per wave (the row-major
-      // numbering of round 1 put up to three panel tiles of a stage on one wave).
-      const int x = sl * TL_CW + wave;
-      live[sl] = x < ntiles;
-      int P = 0, Q = 0;
-      if (live[sl]) {
-        int start = 0;
-        while (Q + 1 < nt && start + (nt - Q) <= x) { start += nt - Q; ++Q; }
-        P = Q + (x - start);
-      }
+      // Ownership: TL_MAP (eaqhm_ls_tilemap.h, generated by tools/tile_map_search.py) — the wave that owns diagonal tile jb
+      // holds few tiles of the trailing matrix of stage jb, so that after diag_D it does not keep the others waiting at the
+      // stage barrier with trailing tiles of its own; at most NS tiles per wave, tile counts per SIMD equal to within one
+      // (the contraction stays balanced), at most ... panel tiles of a column on one wave.  (Rounds 1-2 dealt the tiles
+      // out column by column, tile x on wave x % 8.)
+      const int code = TL_MAP[nt][wave][sl];
+      live[sl] = code != 0xFF;
+      const int P = live[sl] ? (code >> 4) : 0, Q = live[sl] ? (code & 15) : 0;
       tP[sl] = __builtin_amdgcn_readfirstlane(P);   // wave-uniform: scalar registers, not spill slots
       tQ[sl] = __builtin_amdgcn_readfirstlane(Q);
     }
