@@ -393,7 +393,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             atomicAdd(dbg + 13, 1ull);
             *tlast = td1;
           }
-        } else if (wave == (DIAG_OWNER(jb, nt) ^ 1))   // the owner's neighbour builds the inverse
+        } else if (wave == (int)TL_HELP[nt][jb])   // the helper wave builds the inverse (eaqhm_ls_tilemap.h)
           diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
                  (jb == nt - 1) ? is : 16, uni(A.fault));
 #else

@@ -15,7 +15,7 @@ D, ZT, PAN, UPD, BAR = 6750, 800, 2300, 1700, 200      # diag_D, tail of diag_Z,
 TR1, TR2 = 1100, 850                                    # one trailing tile: a wave alone on its SIMD / per tile when the pair shares the pipe
 KAPPA = 0                                               # diag_D slowed per trailing tile of the wave that shares its SIMD
 # (experiments: other constants from the environment, e.g. EAQHM_TM="TR1=1700,TR2=1700,KAPPA=200,OUT=/path/x.h,KEEP=9")
-OUT, KEEP, SEED = None, 0, 0                            # KEEP: sizes up to this many tile rows keep the column-by-column deal
+OUT, KEEP, SEED, ZFREE = None, 0, 0, 0                           # KEEP: sizes up to this many tile rows keep the column-by-column deal
 for kv in os.environ.get("EAQHM_TM", "").split(","):
     if "=" in kv:
         k, v = kv.split("=")
@@ -40,8 +40,8 @@ def stage_times(nt, M):
     out = []
     for jb in range(nt):
         d = M[(jb, jb)]
-        z = d ^ 1
         ntr = [sum(1 for (P, Q) in own[w] if Q >= jb and (P, Q) != (jb, jb)) if jb > 0 else 0 for w in range(WAVES)]
+        z = helper(d, ntr)
         fin = []
         for w in range(WAVES):
             pair = ntr[w] + ntr[(w + 4) % WAVES]
@@ -53,6 +53,26 @@ def stage_times(nt, M):
             fin.append(t)
         pan = max(sum(1 for (P, Q) in own[w] if Q == jb and P > jb) for w in range(WAVES)) * PAN
         out.append(max(fin) + BAR + pan + BAR)
+    return out
+
+
+def helper(d, ntr):
+    """The wave that runs diag_Z beside owner d: ZFREE = 0: its neighbour d ^ 1 (rounds 2-3); 1: the wave on another SIMD
+    with the fewest trailing tiles of its own (it, too, takes them up only after its role)."""
+    if not ZFREE:
+        return d ^ 1
+    cand = [w for w in range(WAVES) if w != d and (w & 3) != (d & 3)]
+    return min(cand, key=lambda w: (ntr[w], (w - d) % WAVES))
+
+
+def helpers(nt, M):
+    own = [[] for _ in range(WAVES)]
+    for t, w in M.items():
+        own[w].append(t)
+    out = []
+    for jb in range(nt):
+        ntr = [sum(1 for (P, Q) in own[w] if Q >= jb and (P, Q) != (jb, jb)) if jb > 0 else 0 for w in range(WAVES)]
+        out.append(helper(M[(jb, jb)], ntr))
     return out
 
 
@@ -118,7 +138,8 @@ def main():
     with open(path, "w") as f:
         f.write("// eaqhm_ls_tilemap.h — GENERATED by tools/tile_map_search.py (do not edit): which wave of eaqhm_ls_tile_kernel holds\n"
                 "// tile (P, Q) of a frame of nt tile rows.  TL_MAP[nt][wave][slot] = (P << 4) | Q, 0xFF = empty slot (a wave's tiles\n"
-                "// fill its first slots); TL_DIAG[nt][jb] = the wave that owns diagonal tile jb.  Searched for short factorisation\n"
+                "// fill its first slots); TL_DIAG[nt][jb] = the wave that owns diagonal tile jb, TL_HELP[nt][jb] = the wave that builds\n"
+                "// its inverse beside it (diag_Z).  Searched for short factorisation\n"
                 "// stages: the owner of a diagonal tile holds few tiles of the trailing matrix of its stage (DESIGN.md section 3.1).\n"
                 "#pragma once\nnamespace eaqhm {\n"
                 "__device__ const unsigned char TL_MAP[14][8][12] = {\n")
@@ -133,6 +154,10 @@ def main():
         for nt in range(14):
             row = [str(maps[nt][(j, j)]) if nt in maps and j < nt else "0" for j in range(13)]
             f.write("  {" + ", ".join(row) + "},\n")
+        f.write("};\n__device__ const unsigned char TL_HELP[14][13] = {\n")
+        for nt in range(14):
+            hz = helpers(nt, maps[nt]) if nt in maps else []
+            f.write("  {" + ", ".join(str(hz[j]) if j < len(hz) else "0" for j in range(13)) + "},\n")
         f.write("};\n}  // namespace eaqhm\n")
     print("wrote", path)
 
