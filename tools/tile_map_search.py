@@ -14,14 +14,17 @@ import numpy as np
 D, ZT, PAN, UPD, BAR = 6750, 800, 2300, 1700, 200      # diag_D, tail of diag_Z, one panel tile, a diagonal tile's update, barrier
 TR1, TR2 = 1100, 850                                    # one trailing tile: a wave alone on its SIMD / per tile when the pair shares the pipe
 KAPPA = 0                                               # diag_D slowed per trailing tile of the wave that shares its SIMD
+NS_OF = {n: 5 for n in range(1, 9)}
+NS_OF.update({9: 6, 10: 7, 11: 9, 12: 10, 13: 12})
 # (experiments: other constants from the environment, e.g. EAQHM_TM="TR1=1700,TR2=1700,KAPPA=200,OUT=/path/x.h,KEEP=9")
 OUT, KEEP, SEED, ZFREE = None, 0, 0, 0                           # KEEP: sizes up to this many tile rows keep the column-by-column deal
 for kv in os.environ.get("EAQHM_TM", "").split(","):
     if "=" in kv:
         k, v = kv.split("=")
-        globals()[k] = v if k == "OUT" else int(v)
-NS_OF = {n: 5 for n in range(1, 9)}
-NS_OF.update({9: 6, 10: 7, 11: 9, 12: 10, 13: 12})
+        if k.startswith("NS") and k[2:].isdigit():
+            NS_OF[int(k[2:])] = int(v)             # (e.g. NS8=6: frames of 8 tile rows on the 6-tile budget)
+        else:
+            globals()[k] = v if k == "OUT" else int(v)
 WAVES = 8
 
 
