@@ -393,9 +393,7 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
             atomicAdd(dbg + 13, 1ull);
             *tlast = td1;
           }
-        } else if (wave == (int)TL_HELP[nt][jb])   // the helper wave builds the inverse (eaqhm_ls_tilemap.h)
-          diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
-                 (jb == nt - 1) ? is : 16, uni(A.fault));
+        }
 #else
         if (mine) asm volatile("" ::"v"(Rt[0]), "v"(It[0]));
 #endif
@@ -408,6 +406,13 @@ __device__ __attribute__((noinline)) void tile_frame(const LsArgs& A, int TS_, i
           }
         }
         STAMP(8);
+#ifndef EAQHM_EXPERIMENT_NODIAG
+        // The helper wave builds the inverse (eaqhm_ls_tilemap.h) — AFTER its own trailing tiles: diag_D's posts wait for
+        // it in LDS and it runs through them without the owner's pace, so its tiles are not what the stage ends on.
+        if (!mine && wave == (int)TL_HELP[nt][jb])
+          diag_Z(post, dflag, 16 * jb, zs, WtR + jb * TL_TILE, WtI + jb * TL_TILE, dorig + 16 * jb,
+                 (jb == nt - 1) ? is : 16, uni(A.fault));
+#endif
         __syncthreads();  // (A) inverse of the diagonal tile published; every read of panel jb-1 done
         STAMP(6);
         // ---- panel tiles (P > jb, Q == jb): X = T W^H, published as Pan[P][k][row]
