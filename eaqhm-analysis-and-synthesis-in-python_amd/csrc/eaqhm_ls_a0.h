@@ -200,9 +200,6 @@ __device__ __attribute__((noinline)) void a0_frame(const LsArgs& A, double* lds_
       }
       if (mine)
         diag_Dr(Rt, post + sp * 256, flags + sp, 16 * jb, dumpD + sp * 64, Ldl + sp * TL_TILE, jb == m - 1);
-      else if (wv == ((yd + 1) & (WPS - 1)))
-        diag_Zr(post + sp * 256, flags + sp, 16 * jb, zs + sp * 64, Wt + (sp * M + jb) * TL_TILE,
-                dorig + sp * 16 * M + 16 * jb, (jb == m - 1) ? is : 16, uni(A.fault));
       A0_STAMP(10);
       if (jb > 0) {
 #pragma unroll
@@ -211,6 +208,10 @@ __device__ __attribute__((noinline)) void a0_frame(const LsArgs& A, double* lds_
           A0_UPDATE(sl)
         }
       }
+      // the helper wave builds the inverse after its own trailing tiles (as in eaqhm_ls_tile_kernel: diag_Dr's posts wait in LDS)
+      if (!mine && wv == ((yd + 1) & (WPS - 1)))
+        diag_Zr(post + sp * 256, flags + sp, 16 * jb, zs + sp * 64, Wt + (sp * M + jb) * TL_TILE,
+                dorig + sp * 16 * M + 16 * jb, (jb == m - 1) ? is : 16, uni(A.fault));
       A0_STAMP(8);
       __syncthreads();  // (A)
       A0_STAMP(6);

@@ -14,6 +14,7 @@ import numpy as np
 D, ZT, PAN, UPD, BAR = 6750, 800, 2300, 1700, 200      # diag_D, tail of diag_Z, one panel tile, a diagonal tile's update, barrier
 TR1, TR2 = 1100, 850                                    # one trailing tile: a wave alone on its SIMD / per tile when the pair shares the pipe
 KAPPA = 0                                               # diag_D slowed per trailing tile of the wave that shares its SIMD
+ZLATE, ZRUN = 0, 4000                                   # 1: model the helper wave as the kernel now runs it (own trailing tiles first, then the eight steps without waiting); the maps kept were searched with 0 and measure better
 NS_OF = {n: 5 for n in range(1, 9)}
 NS_OF.update({9: 6, 10: 7, 11: 9, 12: 10, 13: 12})
 # (experiments: other constants from the environment, e.g. EAQHM_TM="TR1=1700,TR2=1700,KAPPA=200,OUT=/path/x.h,KEEP=9")
@@ -52,7 +53,10 @@ def stage_times(nt, M):
             if w == d:
                 t = (UPD if jb > 0 else 0) + D + KAPPA * ntr[(w + 4) % WAVES] + ntr[w] * TR1
             elif w == z:
-                t = max(t, D + KAPPA * ntr[(d + 4) % WAVES] + (UPD if jb > 0 else 0) + ZT + ntr[w] * TR1)
+                # the helper takes its own trailing tiles FIRST and then runs through diag_D's posts (ZRUN) — or, ZLATE = 0
+                # (the kernel up to the middle of round 3), follows diag_D step by step and takes them afterwards
+                dend = D + KAPPA * ntr[(d + 4) % WAVES] + (UPD if jb > 0 else 0)
+                t = max(t + ZRUN, dend + ZT) if ZLATE else max(t, dend + ZT + ntr[w] * TR1)
             fin.append(t)
         pan = max(sum(1 for (P, Q) in own[w] if Q == jb and P > jb) for w in range(WAVES)) * PAN
         out.append(max(fin) + BAR + pan + BAR)
